@@ -1,0 +1,321 @@
+// BatchNorm2d over NHWC rows (+ fused ReLU / residual add), train + eval forward and backward,
+// and the bias-gradient column sum.  All of it is HBM-bound: 16-byte vector loads, per-thread
+// channel ownership, Welford/Chan statistics in fp32, slice partials combined in a fixed order
+// (bitwise reproducible; no atomics).
+#include "common.h"
+
+struct BnPlan { int cpr, TX, TY, colgroups, nslices, rows_per_slice; };
+
+static BnPlan bn_plan(long rows, int C, int CH) {
+  BnPlan p; p.cpr = C / CH;
+  p.TX = p.cpr < 256 ? p.cpr : 256;
+  // TX must divide 256
+  while (256 % p.TX) --p.TX;
+  p.TY = 256 / p.TX;
+  p.colgroups = cdiv(p.cpr, p.TX);
+  long want = rows / ((long)p.TY * 8); if (want < 1) want = 1;
+  long cap = 1536 / p.colgroups; if (cap < 1) cap = 1;
+  if (want > cap) want = cap;
+  long rps = (rows + want - 1) / want; rps = ((rps + p.TY - 1) / p.TY) * p.TY;
+  p.rows_per_slice = (int)rps; p.nslices = (int)((rows + rps - 1) / rps);
+  return p;
+}
+
+extern "C" size_t mi355_bn_workspace(long rows, int C) {
+  BnPlan p = bn_plan(rows, C, 4);  // fp32 chunking gives the larger plan
+  BnPlan q = bn_plan(rows, C, 8);
+  int ns = p.nslices > q.nslices ? p.nslices : q.nslices;
+  return ((size_t)ns * C * 3 + 4 * (size_t)C) * sizeof(float);
+}
+extern "C" size_t mi355_colsum_workspace(long rows, int C) { return mi355_bn_workspace(rows, C); }
+
+// -------------------------------------------------------------------------------- forward statistics
+// partial[slice][c] = (n, mean, M2)
+template <typename T>
+__global__ __launch_bounds__(256) void bn_stats_kernel(const T* __restrict__ x, float* __restrict__ partial, long rows,
+                                                        int C, int TX, int rows_per_slice) {
+  constexpr int CH = Chunk<T>::N;
+  __shared__ float sh[256 * CH * 2 + 256];
+  const int TY = 256 / TX;
+  const int tx = threadIdx.x % TX, ty = threadIdx.x / TX;
+  const int chunk = blockIdx.x * TX + tx;
+  const bool colok = chunk * CH < C;
+  const long r0 = (long)blockIdx.y * rows_per_slice;
+  long r1 = r0 + rows_per_slice; if (r1 > rows) r1 = rows;
+  float mean[CH], m2[CH];
+#pragma unroll
+  for (int e = 0; e < CH; ++e) { mean[e] = 0.f; m2[e] = 0.f; }
+  float n = 0.f;
+  if (colok)
+    for (long r = r0 + ty; r < r1; r += TY) {
+      float v[CH]; Chunk<T>::load(x + (size_t)r * C + (size_t)chunk * CH, v);
+      n += 1.f; const float inv = 1.f / n;
+#pragma unroll
+      for (int e = 0; e < CH; ++e) { float d = v[e] - mean[e]; mean[e] += d * inv; m2[e] += d * (v[e] - mean[e]); }
+    }
+  // combine the TY row-lanes of each column (Chan et al.), fixed order
+  float* smean = sh; float* sm2 = sh + 256 * CH; float* sn = sh + 512 * CH;
+#pragma unroll
+  for (int e = 0; e < CH; ++e) { smean[threadIdx.x * CH + e] = mean[e]; sm2[threadIdx.x * CH + e] = m2[e]; }
+  sn[threadIdx.x] = n;
+  __syncthreads();
+  if (ty == 0 && colok) {
+    for (int j = 1; j < TY; ++j) {
+      const int o = j * TX + tx; const float nb = sn[o];
+      if (nb > 0.f) {
+        const float nt = n + nb, f = nb / nt;
+#pragma unroll
+        for (int e = 0; e < CH; ++e) {
+          float d = smean[o * CH + e] - mean[e];
+          mean[e] += d * f; m2[e] += sm2[o * CH + e] + d * d * n * f;
+        }
+        n = nt;
+      }
+    }
+    float* out = partial + ((size_t)blockIdx.y * C + (size_t)chunk * CH) * 3;
+#pragma unroll
+    for (int e = 0; e < CH; ++e) { out[e * 3] = n; out[e * 3 + 1] = mean[e]; out[e * 3 + 2] = m2[e]; }
+  }
+}
+
+// one thread per channel: combine slices, update running stats, emit scale/shift
+__global__ void bn_finalize_kernel(const float* __restrict__ partial, int nslices, int C, const float* __restrict__ gamma,
+                                   const float* __restrict__ beta, float* running_mean, float* running_var,
+                                   int64_t* nbt, float* save_mean, float* save_invstd, float* scale_shift, float eps,
+                                   float momentum) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c == 0 && nbt) *nbt += 1;
+  if (c >= C) return;
+  float n = 0.f, mean = 0.f, m2 = 0.f;
+  for (int s = 0; s < nslices; ++s) {
+    const float* q = partial + ((size_t)s * C + c) * 3;
+    const float nb = q[0];
+    if (nb > 0.f) { const float nt = n + nb, f = nb / nt, d = q[1] - mean; mean += d * f; m2 += q[2] + d * d * n * f; n = nt; }
+  }
+  const float var = m2 / n;
+  const float invstd = 1.0f / sqrtf(var + eps);
+  save_mean[c] = mean; save_invstd[c] = invstd;
+  if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
+  if (running_var) running_var[c] = (1.f - momentum) * running_var[c] + momentum * (n > 1.f ? m2 / (n - 1.f) : var);
+  const float sc = gamma[c] * invstd;
+  scale_shift[c] = sc; scale_shift[C + c] = beta[c] - mean * sc;
+}
+
+template <typename T, bool EVAL>
+__global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, const T* __restrict__ res, T* __restrict__ y,
+                                                        const float* __restrict__ scale_shift, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, const float* __restrict__ rm,
+                                                        const float* __restrict__ rv, float eps, long rows, int C, int TX, int relu) {
+  constexpr int CH = Chunk<T>::N;
+  const int TY = 256 / TX;
+  const int tx = threadIdx.x % TX, ty = threadIdx.x / TX;
+  const int chunk = blockIdx.x * TX + tx;
+  if (chunk * CH >= C) return;
+  float sc[CH], sh[CH];
+#pragma unroll
+  for (int e = 0; e < CH; ++e) {
+    const int c = chunk * CH + e;
+    if (EVAL) { sc[e] = gamma[c] / sqrtf(rv[c] + eps); sh[e] = beta[c] - rm[c] * sc[e]; }
+    else { sc[e] = scale_shift[c]; sh[e] = scale_shift[C + c]; }
+  }
+  for (long r = (long)blockIdx.y * TY + ty; r < rows; r += (long)gridDim.y * TY) {
+    const size_t off = (size_t)r * C + (size_t)chunk * CH;
+    float v[CH]; Chunk<T>::load(x + off, v);
+#pragma unroll
+    for (int e = 0; e < CH; ++e) v[e] = v[e] * sc[e] + sh[e];
+    if (res) { float w[CH]; Chunk<T>::load(res + off, w);
+#pragma unroll
+      for (int e = 0; e < CH; ++e) v[e] += w[e]; }
+    if (relu) {
+#pragma unroll
+      for (int e = 0; e < CH; ++e) v[e] = v[e] < 0.f ? 0.f : v[e]; }   // keeps NaN, like ATen relu
+    Chunk<T>::store(y + off, v);
+  }
+}
+
+// -------------------------------------------------------------------------------- backward
+// partial[slice][c] = (sum dy_eff, sum dy_eff * xhat)
+template <typename T, bool XHAT>
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict__ dy, const T* __restrict__ x, const T* __restrict__ y,
+                                                             const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                             float* __restrict__ partial, long rows, int C, int TX, int rows_per_slice, int relu) {
+  constexpr int CH = Chunk<T>::N;
+  __shared__ float sh[256 * CH * 2];
+  const int TY = 256 / TX;
+  const int tx = threadIdx.x % TX, ty = threadIdx.x / TX;
+  const int chunk = blockIdx.x * TX + tx;
+  const bool colok = chunk * CH < C;
+  const long r0 = (long)blockIdx.y * rows_per_slice;
+  long r1 = r0 + rows_per_slice; if (r1 > rows) r1 = rows;
+  float s1[CH], s2[CH], mu[CH], is[CH];
+#pragma unroll
+  for (int e = 0; e < CH; ++e) { s1[e] = 0.f; s2[e] = 0.f; mu[e] = 0.f; is[e] = 0.f; }
+  if (colok && XHAT) {
+#pragma unroll
+    for (int e = 0; e < CH; ++e) { mu[e] = mean[chunk * CH + e]; is[e] = invstd[chunk * CH + e]; }
+  }
+  if (colok)
+    for (long r = r0 + ty; r < r1; r += TY) {
+      const size_t off = (size_t)r * C + (size_t)chunk * CH;
+      float g[CH]; Chunk<T>::load(dy + off, g);
+      if (relu) { float o[CH]; Chunk<T>::load(y + off, o);
+#pragma unroll
+        for (int e = 0; e < CH; ++e) g[e] = o[e] > 0.f ? g[e] : 0.f; }
+      if (XHAT) { float v[CH]; Chunk<T>::load(x + off, v);
+#pragma unroll
+        for (int e = 0; e < CH; ++e) { s1[e] += g[e]; s2[e] += g[e] * ((v[e] - mu[e]) * is[e]); }
+      } else {
+#pragma unroll
+        for (int e = 0; e < CH; ++e) s1[e] += g[e];
+      }
+    }
+#pragma unroll
+  for (int e = 0; e < CH; ++e) { sh[threadIdx.x * CH + e] = s1[e]; sh[256 * CH + threadIdx.x * CH + e] = s2[e]; }
+  __syncthreads();
+  if (ty == 0 && colok) {
+    for (int j = 1; j < TY; ++j) {
+      const int o = j * TX + tx;
+#pragma unroll
+      for (int e = 0; e < CH; ++e) { s1[e] += sh[o * CH + e]; s2[e] += sh[256 * CH + o * CH + e]; }
+    }
+    float* out = partial + ((size_t)blockIdx.y * C + (size_t)chunk * CH) * 2;
+#pragma unroll
+    for (int e = 0; e < CH; ++e) { out[e * 2] = s1[e]; out[e * 2 + 1] = s2[e]; }
+  }
+}
+
+// coeff[c] = (k0 = gamma*invstd, k1 = mean(dy_eff), k2 = mean(dy_eff*xhat)); dgamma/dbeta (=|+=)
+__global__ void bn_bwd_finalize_kernel(const float* __restrict__ partial, int nslices, int C, float inv_rows,
+                                       const float* __restrict__ gamma, const float* __restrict__ invstd, float* dgamma,
+                                       float* dbeta, int accumulate, float* coeff) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float s1 = 0.f, s2 = 0.f;
+  for (int s = 0; s < nslices; ++s) { const float* q = partial + ((size_t)s * C + c) * 2; s1 += q[0]; s2 += q[1]; }
+  if (dbeta) dbeta[c] = (accumulate ? dbeta[c] : 0.f) + s1;
+  if (dgamma) dgamma[c] = (accumulate ? dgamma[c] : 0.f) + s2;
+  if (coeff) { coeff[c] = gamma[c] * invstd[c]; coeff[C + c] = s1 * inv_rows; coeff[2 * C + c] = s2 * inv_rows; }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ dy, const T* __restrict__ x, const T* __restrict__ y,
+                                                            const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                            const float* __restrict__ coeff, T* __restrict__ dx, T* __restrict__ dres,
+                                                            long rows, int C, int TX, int relu) {
+  constexpr int CH = Chunk<T>::N;
+  const int TY = 256 / TX;
+  const int tx = threadIdx.x % TX, ty = threadIdx.x / TX;
+  const int chunk = blockIdx.x * TX + tx;
+  if (chunk * CH >= C) return;
+  float k0[CH], k1[CH], k2[CH], mu[CH], is[CH];
+#pragma unroll
+  for (int e = 0; e < CH; ++e) {
+    const int c = chunk * CH + e;
+    k0[e] = coeff[c]; k1[e] = coeff[C + c]; k2[e] = coeff[2 * C + c]; mu[e] = mean[c]; is[e] = invstd[c];
+  }
+  for (long r = (long)blockIdx.y * TY + ty; r < rows; r += (long)gridDim.y * TY) {
+    const size_t off = (size_t)r * C + (size_t)chunk * CH;
+    float g[CH], v[CH]; Chunk<T>::load(dy + off, g); Chunk<T>::load(x + off, v);
+    if (relu) { float o[CH]; Chunk<T>::load(y + off, o);
+#pragma unroll
+      for (int e = 0; e < CH; ++e) g[e] = o[e] > 0.f ? g[e] : 0.f; }
+    if (dres) Chunk<T>::store(dres + off, g);
+#pragma unroll
+    for (int e = 0; e < CH; ++e) v[e] = k0[e] * (g[e] - k1[e] - (v[e] - mu[e]) * is[e] * k2[e]);
+    Chunk<T>::store(dx + off, v);
+  }
+}
+
+__global__ void colsum_finalize_kernel(const float* __restrict__ partial, int nslices, int C, float* out, int accumulate) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float s = 0.f;
+  for (int i = 0; i < nslices; ++i) s += partial[((size_t)i * C + c) * 2];
+  out[c] = (accumulate ? out[c] : 0.f) + s;
+}
+
+// -------------------------------------------------------------------------------- host
+static int bn_check(long rows, int C, int dtype, int* CH) {
+  if (dtype != MI355_F32 && dtype != MI355_BF16) MI_FAIL(MI355_EINVAL, "bn: bad dtype");
+  *CH = dtype == MI355_BF16 ? 8 : 4;
+  if (rows < 1 || C < 1 || C % *CH) MI_FAIL(MI355_EINVAL, "bn: C=%d must be a positive multiple of %d (rows=%ld)", C, *CH, rows);
+  return 0;
+}
+static dim3 apply_grid(const BnPlan& p, long rows) {
+  long gy = rows / ((long)p.TY * 4); if (gy < 1) gy = 1;
+  long cap = 2048 / p.colgroups; if (cap < 1) cap = 1;
+  if (gy > cap) gy = cap;
+  return dim3(p.colgroups, (unsigned)gy);
+}
+
+extern "C" int mi355_bn_train_fwd(const void* x, const void* residual, void* y, const float* gamma, const float* beta,
+                                  float* running_mean, float* running_var, int64_t* nbt, float* save_mean, float* save_invstd,
+                                  long rows, int C, float eps, float momentum, int relu, int dtype, void* ws, size_t ws_bytes,
+                                  void* stream) {
+  int CH; if (int e = bn_check(rows, C, dtype, &CH)) return e;
+  if (!ws || ws_bytes < mi355_bn_workspace(rows, C)) MI_FAIL(MI355_EWORKSPACE, "bn_train_fwd: workspace too small");
+  hipStream_t st = as_stream(stream);
+  BnPlan p = bn_plan(rows, C, CH);
+  float* partial = reinterpret_cast<float*>(ws);
+  float* ss = partial + (size_t)p.nslices * C * 3;
+  dim3 g(p.colgroups, p.nslices);
+  if (dtype == MI355_BF16) hipLaunchKernelGGL(bn_stats_kernel<bf16_t>, g, dim3(256), 0, st, (const bf16_t*)x, partial, rows, C, p.TX, p.rows_per_slice);
+  else hipLaunchKernelGGL(bn_stats_kernel<float>, g, dim3(256), 0, st, (const float*)x, partial, rows, C, p.TX, p.rows_per_slice);
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 256)), dim3(256), 0, st, partial, p.nslices, C, gamma, beta, running_mean, running_var, nbt, save_mean, save_invstd, ss, eps, momentum);
+  dim3 ga = apply_grid(p, rows);
+  const float* nf = nullptr;
+  if (dtype == MI355_BF16) hipLaunchKernelGGL((bn_apply_kernel<bf16_t, false>), ga, dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)residual, (bf16_t*)y, (const float*)ss, nf, nf, nf, nf, eps, rows, C, p.TX, relu);
+  else hipLaunchKernelGGL((bn_apply_kernel<float, false>), ga, dim3(256), 0, st, (const float*)x, (const float*)residual, (float*)y, (const float*)ss, nf, nf, nf, nf, eps, rows, C, p.TX, relu);
+  MI_CHECK_LAUNCH("bn_train_fwd");
+  return MI355_OK;
+}
+
+extern "C" int mi355_bn_eval_fwd(const void* x, const void* residual, void* y, const float* gamma, const float* beta,
+                                 const float* running_mean, const float* running_var, long rows, int C, float eps, int relu,
+                                 int dtype, void* stream) {
+  int CH; if (int e = bn_check(rows, C, dtype, &CH)) return e;
+  hipStream_t st = as_stream(stream);
+  BnPlan p = bn_plan(rows, C, CH);
+  dim3 ga = apply_grid(p, rows);
+  const float* nf = nullptr;
+  if (dtype == MI355_BF16) hipLaunchKernelGGL((bn_apply_kernel<bf16_t, true>), ga, dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)residual, (bf16_t*)y, nf, gamma, beta, running_mean, running_var, eps, rows, C, p.TX, relu);
+  else hipLaunchKernelGGL((bn_apply_kernel<float, true>), ga, dim3(256), 0, st, (const float*)x, (const float*)residual, (float*)y, nf, gamma, beta, running_mean, running_var, eps, rows, C, p.TX, relu);
+  MI_CHECK_LAUNCH("bn_eval_fwd");
+  return MI355_OK;
+}
+
+extern "C" int mi355_bn_bwd(const void* dy, const void* x, const void* y, const float* gamma, const float* save_mean,
+                            const float* save_invstd, void* dx, void* dresidual, float* dgamma, float* dbeta, int accumulate,
+                            long rows, int C, int relu, int dtype, void* ws, size_t ws_bytes, void* stream) {
+  int CH; if (int e = bn_check(rows, C, dtype, &CH)) return e;
+  if (!ws || ws_bytes < mi355_bn_workspace(rows, C)) MI_FAIL(MI355_EWORKSPACE, "bn_bwd: workspace too small");
+  if (relu && !y) MI_FAIL(MI355_EINVAL, "bn_bwd: relu needs y");
+  hipStream_t st = as_stream(stream);
+  BnPlan p = bn_plan(rows, C, CH);
+  float* partial = reinterpret_cast<float*>(ws);
+  float* coeff = partial + (size_t)p.nslices * C * 3;   // 3*C floats (4*C reserved)
+  dim3 g(p.colgroups, p.nslices);
+  if (dtype == MI355_BF16) hipLaunchKernelGGL((bn_bwd_reduce_kernel<bf16_t, true>), g, dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)x, (const bf16_t*)y, save_mean, save_invstd, partial, rows, C, p.TX, p.rows_per_slice, relu);
+  else hipLaunchKernelGGL((bn_bwd_reduce_kernel<float, true>), g, dim3(256), 0, st, (const float*)dy, (const float*)x, (const float*)y, save_mean, save_invstd, partial, rows, C, p.TX, p.rows_per_slice, relu);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 256)), dim3(256), 0, st, partial, p.nslices, C, 1.0f / (float)rows, gamma, save_invstd, dgamma, dbeta, accumulate, coeff);
+  dim3 ga = apply_grid(p, rows);
+  if (dtype == MI355_BF16) hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, ga, dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)x, (const bf16_t*)y, save_mean, save_invstd, coeff, (bf16_t*)dx, (bf16_t*)dresidual, rows, C, p.TX, relu);
+  else hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, ga, dim3(256), 0, st, (const float*)dy, (const float*)x, (const float*)y, save_mean, save_invstd, coeff, (float*)dx, (float*)dresidual, rows, C, p.TX, relu);
+  MI_CHECK_LAUNCH("bn_bwd");
+  return MI355_OK;
+}
+
+extern "C" int mi355_colsum(const void* dy, float* out, long rows, int C, int dtype, int accumulate, void* ws, size_t ws_bytes,
+                            void* stream) {
+  int CH; if (int e = bn_check(rows, C, dtype, &CH)) return e;
+  if (!ws || ws_bytes < mi355_colsum_workspace(rows, C)) MI_FAIL(MI355_EWORKSPACE, "colsum: workspace too small");
+  hipStream_t st = as_stream(stream);
+  BnPlan p = bn_plan(rows, C, CH);
+  float* partial = reinterpret_cast<float*>(ws);
+  dim3 g(p.colgroups, p.nslices);
+  if (dtype == MI355_BF16) hipLaunchKernelGGL((bn_bwd_reduce_kernel<bf16_t, false>), g, dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)nullptr, (const bf16_t*)nullptr, (const float*)nullptr, (const float*)nullptr, partial, rows, C, p.TX, p.rows_per_slice, 0);
+  else hipLaunchKernelGGL((bn_bwd_reduce_kernel<float, false>), g, dim3(256), 0, st, (const float*)dy, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, partial, rows, C, p.TX, p.rows_per_slice, 0);
+  hipLaunchKernelGGL(colsum_finalize_kernel, dim3(cdiv(C, 256)), dim3(256), 0, st, partial, p.nslices, C, out, accumulate);
+  MI_CHECK_LAUNCH("colsum");
+  return MI355_OK;
+}

@@ -1,0 +1,237 @@
+// Heat-map row kernels (rows = B*K maps of H*W fp32): hard arg-max (bit-exact with numpy), soft-arg-max,
+// fused log-softmax + KL loss (+ its gradient), pseudo-label builders, bilinear up-sampling, PCK distances.
+// One 256-thread workgroup per map, wave-shuffle reductions; all HBM/L2-bound.
+#include "common.h"
+
+struct ArgBest { float v; int i; };
+__device__ __forceinline__ bool arg_better(float av, int ai, float bv, int bi) {
+  const bool an = av != av, bn = bv != bv;
+  if (an || bn) return (an && !bn) || (an && bn && ai < bi);
+  return av > bv || (av == bv && ai < bi);
+}
+
+// utils/keypoint_detection.py:7-35
+__global__ __launch_bounds__(256) void argmax2d_kernel(const float* __restrict__ hm, int* __restrict__ idx, float* __restrict__ xy,
+                                                        float* __restrict__ maxval, int HW, int W) {
+  __shared__ float sv[4]; __shared__ int si[4];
+  const float* row = hm + (size_t)blockIdx.x * HW;
+  float bv = row[0]; int bi = 0;
+  if (threadIdx.x < HW) { bv = row[threadIdx.x]; bi = threadIdx.x; }
+  for (int i = threadIdx.x + 256; i < HW; i += 256) { const float v = row[i]; if (arg_better(v, i, bv, bi)) { bv = v; bi = i; } }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ov = __shfl_xor(bv, o, 64); const int oi = __shfl_xor(bi, o, 64);
+    if (arg_better(ov, oi, bv, bi)) { bv = ov; bi = oi; }
+  }
+  if ((threadIdx.x & 63) == 0) { sv[threadIdx.x >> 6] = bv; si[threadIdx.x >> 6] = bi; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < 4; ++w) if (arg_better(sv[w], si[w], bv, bi)) { bv = sv[w]; bi = si[w]; }
+    const bool pos = bv > 0.0f;                       // np.greater(maxvals, 0.0): NaN -> False
+    if (idx) idx[blockIdx.x] = bi;
+    if (maxval) maxval[blockIdx.x] = bv;
+    if (xy) { xy[2 * blockIdx.x] = pos ? (float)(bi % W) : 0.f; xy[2 * blockIdx.x + 1] = pos ? (float)(bi / W) : 0.f; }
+  }
+}
+
+// utils/keypoint_detection.py:209-239
+__global__ __launch_bounds__(256) void softargmax_kernel(const float* __restrict__ hm, float* __restrict__ uv, int HW, int W, float beta,
+                                                          float out_scale) {
+  __shared__ float red[4];
+  const float* row = hm + (size_t)blockIdx.x * HW;
+  float m = -INFINITY;
+  for (int i = threadIdx.x; i < HW; i += 256) m = fmaxf(m, row[i] * beta);
+  m = block_max<4>(m, red);
+  float s = 0.f, su = 0.f, sv = 0.f;
+  for (int i = threadIdx.x; i < HW; i += 256) {
+    const float e = expf(row[i] * beta - m);
+    s += e; su += e * (float)(i % W); sv += e * (float)(i / W);
+  }
+  s = block_sum<4>(s, red); su = block_sum<4>(su, red); sv = block_sum<4>(sv, red);
+  if (threadIdx.x == 0) { uv[2 * blockIdx.x] = su / s * out_scale; uv[2 * blockIdx.x + 1] = sv / s * out_scale; }
+}
+
+// uda/model/loss.py:145-158 (+ d(mean loss)/d pred)
+__global__ __launch_bounds__(256) void kl_heatmap_kernel(const float* __restrict__ pred, const float* __restrict__ target,
+                                                          const float* __restrict__ weight, float eps, float* __restrict__ loss_rows,
+                                                          float* __restrict__ unit_grad, int HW, float inv_count) {
+  __shared__ float red[4];
+  const size_t base = (size_t)blockIdx.x * HW;
+  const float* p = pred + base; const float* t = target + base;
+  float m = -INFINITY, ts = 0.f;
+  for (int i = threadIdx.x; i < HW; i += 256) { m = fmaxf(m, p[i]); ts += t[i] + eps; }
+  m = block_max<4>(m, red);
+  ts = block_sum<4>(ts, red);
+  float se = 0.f;
+  for (int i = threadIdx.x; i < HW; i += 256) se += expf(p[i] - m);
+  se = block_sum<4>(se, red);
+  const float lse = logf(se);
+  float l = 0.f, tn_sum = 0.f;
+  for (int i = threadIdx.x; i < HW; i += 256) {
+    const float tn = (t[i] + eps) / ts;
+    const float logp = p[i] - m - lse;
+    // nn.KLDivLoss pointwise: xlogy(t,t) - t*logp  (xlogy(0,0) = 0; NaN propagates)
+    const float xl = (tn == 0.f) ? 0.f : tn * logf(tn);
+    l += xl - tn * logp;
+    tn_sum += tn;
+  }
+  l = block_sum<4>(l, red);
+  tn_sum = block_sum<4>(tn_sum, red);
+  const float w = weight ? weight[blockIdx.x] : 1.f;
+  if (threadIdx.x == 0) loss_rows[blockIdx.x] = l * w;
+  if (unit_grad) {
+    float* g = unit_grad + base;
+    const float k = w * inv_count;
+    for (int i = threadIdx.x; i < HW; i += 256) {
+      const float tn = (t[i] + eps) / ts;
+      const float sm = expf(p[i] - m - lse);
+      g[i] = k * (sm * tn_sum - tn);
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void reduce_sum_kernel(const float* __restrict__ in, float* __restrict__ out, int n, float scale) {
+  __shared__ float red[4];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) s += in[i];
+  s = block_sum<4>(s, red);
+  if (threadIdx.x == 0) out[0] = s * scale;
+}
+
+__global__ void scale_by_dev_kernel(const float* __restrict__ in, const float* __restrict__ g, float* __restrict__ out, long n) {
+  const float k = *g;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) out[i] = in[i] * k;
+}
+
+// Pseudo labels (see mi355pose.h).  One block per (b,k) map.
+__global__ __launch_bounds__(256) void pseudo_label_kernel(const float* __restrict__ xy, const float* __restrict__ patch, int radius, int div,
+                                                            int S, int kind, const float* __restrict__ extra, int normalise,
+                                                            float* __restrict__ gt, float* __restrict__ gf, int K) {
+  __shared__ int cx[64], cy[64];
+  __shared__ float spatch[13 * 13];
+  __shared__ float red[4];
+  const int b = blockIdx.x / K, k = blockIdx.x % K;
+  const int side = 2 * radius + 1;
+  if (threadIdx.x < K) {
+    const float x = xy[2 * (b * K + threadIdx.x)], y = xy[2 * (b * K + threadIdx.x) + 1];
+    cx[threadIdx.x] = (int)(x / (float)div); cy[threadIdx.x] = (int)(y / (float)div);   // .astype(int): truncation
+  }
+  for (int i = threadIdx.x; i < side * side; i += 256) spatch[i] = patch[i];
+  __syncthreads();
+  const size_t base = (size_t)blockIdx.x * S * S;
+  auto gauss = [&](int j, int px, int py) -> float {
+    const int dx = px - cx[j] + radius, dy = py - cy[j] + radius;
+    return (dx >= 0 && dx < side && dy >= 0 && dy < side) ? spatch[dy * side + dx] : 0.f;
+  };
+  float mx = -INFINITY;
+  for (int i = threadIdx.x; i < S * S; i += 256) {
+    const int px = i % S, py = i / S;
+    const float g = gauss(k, px, py);
+    if (gt) gt[base + i] = g;
+    if (gf) {
+      float f;
+      if (kind == 1) f = fminf(fmaxf(1.f - g * 10.f, 0.f), 1.f);
+      else {
+        float s = 0.f;
+        if (kind == 0) { for (int j = 0; j < K; ++j) if (j != k) s += gauss(j, px, py); f = fminf(fmaxf(s, 0.f), 1.f); }
+        else { for (int j = 0; j < K; ++j) s += gauss(j, px, py); f = fminf(fmaxf(fminf(fmaxf(s, 0.f), 1.f) - g * 10.f, 0.f), 1.f); }
+      }
+      if (extra) f = fminf(fmaxf(f + extra[base + i] - g * 100.f, 0.f), 1.f);
+      gf[base + i] = f;
+      mx = fmaxf(mx, f);     // fmaxf drops NaN like torch.max? torch.max propagates NaN; extra is finite in practice
+    }
+  }
+  if (gf && normalise) {
+    mx = block_max<4>(mx, red);
+    __syncthreads();
+    for (int i = threadIdx.x; i < S * S; i += 256) gf[base + i] = gf[base + i] / mx;   // 0/0 -> NaN as the reference
+  }
+}
+
+// nn.Upsample(size, mode='bilinear'), align_corners=False (ATen upsample_bilinear2d index rule)
+__global__ void bilinear_up_kernel(const float* __restrict__ in, float* __restrict__ out, int rows, int h, int w, int H, int W,
+                                   float alpha, int accumulate) {
+  const long total = (long)rows * H * W;
+  const float sy = (float)h / (float)H, sx = (float)w / (float)W;
+  for (long id = (long)blockIdx.x * blockDim.x + threadIdx.x; id < total; id += (long)gridDim.x * blockDim.x) {
+    const int ox = (int)(id % W); long r = id / W; const int oy = (int)(r % H); const int row = (int)(r / H);
+    float fy = sy * ((float)oy + 0.5f) - 0.5f; if (fy < 0.f) fy = 0.f;
+    float fx = sx * ((float)ox + 0.5f) - 0.5f; if (fx < 0.f) fx = 0.f;
+    const int y0 = (int)fy, x0 = (int)fx;
+    const int y1 = y0 + ((y0 < h - 1) ? 1 : 0), x1 = x0 + ((x0 < w - 1) ? 1 : 0);
+    const float ly = fy - (float)y0, lx = fx - (float)x0, hy = 1.f - ly, hx = 1.f - lx;
+    const float* src = in + (size_t)row * h * w;
+    const float v = hy * (hx * src[y0 * w + x0] + lx * src[y0 * w + x1]) + ly * (hx * src[y1 * w + x0] + lx * src[y1 * w + x1]);
+    out[id] = alpha * v + (accumulate ? out[id] : 0.f);
+  }
+}
+
+// utils/keypoint_detection.py:38-50 (float64 arithmetic like numpy)
+__global__ void pck_dists_kernel(const float* __restrict__ pred, const float* __restrict__ tgt, float* __restrict__ dists, int rows,
+                                 float nx, float ny) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= rows) return;
+  const float tx = tgt[2 * r], ty = tgt[2 * r + 1];
+  float d = -1.f;
+  if (tx > 1.f && ty > 1.f) {
+    const double dx = (double)pred[2 * r] / (double)nx - (double)tx / (double)nx;
+    const double dy = (double)pred[2 * r + 1] / (double)ny - (double)ty / (double)ny;
+    d = (float)sqrt(dx * dx + dy * dy);
+  }
+  dists[r] = d;
+}
+
+// ---------------------------------------------------------------------------------------- host
+extern "C" int mi355_argmax2d(const float* hm, int32_t* idx, float* xy, float* maxval, int rows, int H, int W, void* stream) {
+  if (!hm || rows < 1 || H < 1 || W < 1) MI_FAIL(MI355_EINVAL, "argmax2d: bad args");
+  hipLaunchKernelGGL(argmax2d_kernel, dim3(rows), dim3(256), 0, as_stream(stream), hm, idx, xy, maxval, H * W, W);
+  MI_CHECK_LAUNCH("argmax2d");
+  return MI355_OK;
+}
+extern "C" int mi355_softargmax(const float* hm, float* uv, int rows, int H, int W, float beta, float out_scale, void* stream) {
+  if (!hm || !uv || rows < 1 || H < 1 || W < 1) MI_FAIL(MI355_EINVAL, "softargmax: bad args");
+  hipLaunchKernelGGL(softargmax_kernel, dim3(rows), dim3(256), 0, as_stream(stream), hm, uv, H * W, W, beta, out_scale);
+  MI_CHECK_LAUNCH("softargmax");
+  return MI355_OK;
+}
+extern "C" int mi355_kl_heatmap(const float* pred, const float* target, const float* weight, float eps, float* loss_rows,
+                                float* unit_grad, int rows, int HW, float inv_count, void* stream) {
+  if (!pred || !target || !loss_rows || rows < 1 || HW < 1) MI_FAIL(MI355_EINVAL, "kl_heatmap: bad args");
+  hipLaunchKernelGGL(kl_heatmap_kernel, dim3(rows), dim3(256), 0, as_stream(stream), pred, target, weight, eps, loss_rows, unit_grad, HW, inv_count);
+  MI_CHECK_LAUNCH("kl_heatmap");
+  return MI355_OK;
+}
+extern "C" int mi355_reduce_sum(const float* in, float* out, int n, float scale, void* stream) {
+  if (!in || !out || n < 1) MI_FAIL(MI355_EINVAL, "reduce_sum: bad args");
+  hipLaunchKernelGGL(reduce_sum_kernel, dim3(1), dim3(256), 0, as_stream(stream), in, out, n, scale);
+  MI_CHECK_LAUNCH("reduce_sum");
+  return MI355_OK;
+}
+extern "C" int mi355_scale_by_dev(const float* in, const float* g_dev, float* out, long n, void* stream) {
+  if (!in || !out || !g_dev || n < 1) MI_FAIL(MI355_EINVAL, "scale_by_dev: bad args");
+  int grid = (int)((n + 255) / 256); if (grid > 4096) grid = 4096;
+  hipLaunchKernelGGL(scale_by_dev_kernel, dim3(grid), dim3(256), 0, as_stream(stream), in, g_dev, out, n);
+  MI_CHECK_LAUNCH("scale_by_dev");
+  return MI355_OK;
+}
+extern "C" int mi355_pseudo_label(const float* xy, const float* patch, int radius, int div, int S, int kind, const float* extra,
+                                  int normalise, float* gt, float* gf, int B, int K, void* stream) {
+  if (!xy || !patch || radius < 0 || radius > 6 || div < 1 || S < 1 || kind < 0 || kind > 2 || B < 1 || K < 1 || K > 64)
+    MI_FAIL(MI355_EINVAL, "pseudo_label: bad args (radius=%d div=%d S=%d kind=%d B=%d K=%d)", radius, div, S, kind, B, K);
+  hipLaunchKernelGGL(pseudo_label_kernel, dim3(B * K), dim3(256), 0, as_stream(stream), xy, patch, radius, div, S, kind, extra, normalise, gt, gf, K);
+  MI_CHECK_LAUNCH("pseudo_label");
+  return MI355_OK;
+}
+extern "C" int mi355_bilinear_up(const float* in, float* out, int rows, int h, int w, int H, int W, float alpha, int accumulate, void* stream) {
+  if (!in || !out || rows < 1 || h < 1 || w < 1 || H < 1 || W < 1) MI_FAIL(MI355_EINVAL, "bilinear_up: bad args");
+  long total = (long)rows * H * W; int grid = (int)((total + 255) / 256); if (grid > 4096) grid = 4096;
+  hipLaunchKernelGGL(bilinear_up_kernel, dim3(grid), dim3(256), 0, as_stream(stream), in, out, rows, h, w, H, W, alpha, accumulate);
+  MI_CHECK_LAUNCH("bilinear_up");
+  return MI355_OK;
+}
+extern "C" int mi355_pck_dists(const float* pred_xy, const float* tgt_xy, float* dists, int rows, float norm_x, float norm_y, void* stream) {
+  if (!pred_xy || !tgt_xy || !dists || rows < 1) MI_FAIL(MI355_EINVAL, "pck_dists: bad args");
+  hipLaunchKernelGGL(pck_dists_kernel, dim3(cdiv(rows, 256)), dim3(256), 0, as_stream(stream), pred_xy, tgt_xy, dists, rows, norm_x, norm_y);
+  MI_CHECK_LAUNCH("pck_dists");
+  return MI355_OK;
+}

@@ -1,0 +1,569 @@
+// Implicit-GEMM convolution family on MFMA (gfx950):
+//   gather-GEMM  : D[m][n] = sum_{tap} sum_c A[pix(m)+off(tap)][c] * B[n][tap][c]
+//                  -> conv-form forward, and (per stride phase) conv-form dgrad / ConvTranspose fwd
+//   wgrad-GEMM   : dW[o][tap][c] = sum_m DY[m][o] * X[pix(m)+off(tap)][c]   (split over m, slab reduce)
+// Layout: activations NHWC, K (channels) contiguous, 16-byte chunks; tiles staged through LDS in
+// 128-byte rows with an XOR swizzle so that ds_read_b128 fragment reads are conflict-free.
+// bf16: v_mfma_f32_32x32x16_bf16, fp32 accumulate.  f32: v_mfma_f32_32x32x2_f32 (exact fp32, parity path).
+#include "common.h"
+
+#define MAX_TAPS 52
+struct Tap { int8_t dy, dx; int16_t widx; };
+
+struct GatherArgs {
+  const void* A; const void* B; void* D;
+  const float* bias; const void* residual; const float* scale;
+  int Hi, Wi, Ci;
+  int OHp, OWp;
+  int in_sy, in_sx;
+  int Ho, Wo;
+  int out_sy, out_sx, out_oy, out_ox;
+  int Nout, ldb, ldd;
+  int ntaps, cshift, kchunks;
+  int M;
+  int accumulate;
+  int ntm, ntn;
+  Tap taps[MAX_TAPS];
+};
+
+// swizzled byte offset of 16-byte chunk `c` (0..7) in 128-byte row `r`
+__device__ __forceinline__ int swz128(int r, int c) { return r * 128 + ((c ^ ((r >> 1) & 7)) << 4); }
+
+// XCD-aware bijective remap of the linear block id (blocks b and b+8 share an XCD / L2).
+__device__ __forceinline__ int xcd_remap(int bid, int nblk) {
+  int q = nblk >> 3, r = nblk & 7, x = bid & 7, i = bid >> 3;
+  int start = (x < r) ? x * (q + 1) : r * (q + 1) + (x - r) * q;
+  return start + i;
+}
+
+template <typename T> struct MmaTraits;
+template <> struct MmaTraits<bf16_t> { static constexpr int BK = 64; static constexpr int CH = 8; };
+template <> struct MmaTraits<float> { static constexpr int BK = 32; static constexpr int CH = 4; };
+
+template <typename T, int BM, int BN>
+struct GatherSmem {
+  static constexpr int kStage = (BM + BN) * 128;
+  static constexpr int kOutStride = BN * (int)sizeof(T) + 16;
+  static constexpr int kOut = BM * kOutStride;
+  static constexpr int kBytes = (2 * kStage > kOut ? 2 * kStage : kOut) + BM * 4;
+};
+
+template <typename T, int BM, int BN, bool SMALL_C>
+__global__ __launch_bounds__(256) void gather_gemm_kernel(const GatherArgs p) {
+  constexpr int CH = MmaTraits<T>::CH;
+  constexpr int WM = BM / 2, WN = BN / 2, MT = WM / 32, NT = WN / 32;
+  constexpr int RA = BM / 32, RB = BN / 32;
+  using SM = GatherSmem<T, BM, BN>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  int* row_off = reinterpret_cast<int*>(smem + SM::kBytes - BM * 4);
+
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int nblk = p.ntm * p.ntn;
+  const int tile = xcd_remap(blockIdx.x, nblk);
+  const int m0 = (tile / p.ntn) * BM, n0 = (tile % p.ntn) * BN;
+  const int wm0 = (wave >> 1) * WM, wn0 = (wave & 1) * WN;
+  const int lc = t & 7, lr = t >> 3;
+
+  const T* __restrict__ A = reinterpret_cast<const T*>(p.A);
+  const T* __restrict__ B = reinterpret_cast<const T*>(p.B);
+
+  // decode this thread's A rows once
+  int iy0[RA], ix0[RA], abase[RA];
+#pragma unroll
+  for (int i = 0; i < RA; ++i) {
+    int m = m0 + lr + 32 * i;
+    if (m < p.M) {
+      int ox = m % p.OWp, r = m / p.OWp, oy = r % p.OHp, n = r / p.OHp;
+      iy0[i] = oy * p.in_sy; ix0[i] = ox * p.in_sx; abase[i] = n * p.Hi * p.Wi;
+    } else { iy0[i] = -(1 << 20); ix0[i] = 0; abase[i] = 0; }
+  }
+  if (t < BM) {  // output pixel offset (elements) of every tile row, -1 when out of range
+    int m = m0 + t, off = -1;
+    if (m < p.M) {
+      int ox = m % p.OWp, r = m / p.OWp, oy = r % p.OHp, n = r / p.OHp;
+      off = ((n * p.Ho + oy * p.out_sy + p.out_oy) * p.Wo + ox * p.out_sx + p.out_ox) * p.ldd;
+    }
+    row_off[t] = off;
+  }
+
+  uint4 ra[RA], rb[RB];
+  const int cmask = (1 << p.cshift) - 1;
+  auto load_tile = [&](int kt) {
+    int q, tap, cc; bool okq;
+    if (SMALL_C) { q = kt * 8 + lc; okq = q < p.kchunks; tap = okq ? (q >> p.cshift) : 0; cc = (q & cmask) * CH; }
+    else { int q0 = kt * 8; tap = q0 >> p.cshift; cc = ((q0 & cmask) + lc) * CH; okq = true; }
+    const Tap tp = p.taps[tap];
+    const int koff = (int)tp.widx * p.Ci + cc;
+#pragma unroll
+    for (int i = 0; i < RA; ++i) {
+      int iy = iy0[i] + tp.dy, ix = ix0[i] + tp.dx;
+      bool ok = okq && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
+      ra[i] = make_uint4(0, 0, 0, 0);
+      if (ok) ra[i] = *reinterpret_cast<const uint4*>(A + ((size_t)(abase[i] + iy * p.Wi + ix) * p.Ci + cc));
+    }
+#pragma unroll
+    for (int i = 0; i < RB; ++i) {
+      int n = n0 + lr + 32 * i;
+      rb[i] = make_uint4(0, 0, 0, 0);
+      if (okq && n < p.Nout) rb[i] = *reinterpret_cast<const uint4*>(B + ((size_t)n * p.ldb + koff));
+    }
+  };
+  auto store_tile = [&](int stage) {
+    char* as = smem + stage * SM::kStage;
+    char* bs = as + BM * 128;
+#pragma unroll
+    for (int i = 0; i < RA; ++i) *reinterpret_cast<uint4*>(as + swz128(lr + 32 * i, lc)) = ra[i];
+#pragma unroll
+    for (int i = 0; i < RB; ++i) *reinterpret_cast<uint4*>(bs + swz128(lr + 32 * i, lc)) = rb[i];
+  };
+
+  f32x16_t acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int nk = (p.kchunks + 7) >> 3;
+  load_tile(0);
+  store_tile(0);
+  __syncthreads();
+  const int r31 = lane & 31, hi = lane >> 5;
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nk) load_tile(kt + 1);
+    const char* as = smem + cur * SM::kStage;
+    const char* bs = as + BM * 128;
+    if constexpr (sizeof(T) == 2) {
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        bf16x8_t a[MT], b[NT];
+#pragma unroll
+        for (int i = 0; i < MT; ++i) a[i] = *reinterpret_cast<const bf16x8_t*>(as + swz128(wm0 + i * 32 + r31, 2 * s + hi));
+#pragma unroll
+        for (int j = 0; j < NT; ++j) b[j] = *reinterpret_cast<const bf16x8_t*>(bs + swz128(wn0 + j * 32 + r31, 2 * s + hi));
+        // operands swapped: acc holds D^T (lane = m row, registers = 4-wide runs of n) for a wide epilogue
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[j], a[i], acc[i][j], 0, 0, 0);
+      }
+    } else {
+#pragma unroll
+      for (int s = 0; s < 16; ++s) {
+        const int e = 2 * s + hi;
+        float a[MT], b[NT];
+#pragma unroll
+        for (int i = 0; i < MT; ++i) a[i] = *reinterpret_cast<const float*>(as + swz128(wm0 + i * 32 + r31, e >> 2) + (e & 3) * 4);
+#pragma unroll
+        for (int j = 0; j < NT; ++j) b[j] = *reinterpret_cast<const float*>(bs + swz128(wn0 + j * 32 + r31, e >> 2) + (e & 3) * 4);
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[j], a[i], acc[i][j], 0, 0, 0);
+      }
+    }
+    if (kt + 1 < nk) store_tile(cur ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: (acc + bias) * scale -> T -> LDS tile -> coalesced 16-byte rows (+residual / +dx)
+  const float scale = p.scale ? *p.scale : 1.0f;
+  char* outs = smem;
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int ml = wm0 + i * 32 + r31;
+        const int nl = wn0 + j * 32 + 8 * g + 4 * hi;
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float b = (p.bias && (n0 + nl + e) < p.Nout) ? p.bias[n0 + nl + e] : 0.f;
+          v[e] = (acc[i][j][4 * g + e] + b) * scale;
+        }
+        char* dst = outs + ml * SM::kOutStride + nl * (int)sizeof(T);
+        if constexpr (sizeof(T) == 2) {
+          union { bf16_t h[4]; uint2 q; } u;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) u.h[e] = (bf16_t)v[e];
+          *reinterpret_cast<uint2*>(dst) = u.q;
+        } else {
+          *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+        }
+      }
+  __syncthreads();
+  constexpr int CPR = BN / CH;  // 16-byte chunks per tile row
+  T* __restrict__ D = reinterpret_cast<T*>(p.D);
+  const T* __restrict__ R = reinterpret_cast<const T*>(p.residual);
+  for (int id = t; id < BM * CPR; id += 256) {
+    const int r = id / CPR, c = id % CPR;
+    const int off = row_off[r];
+    const int n = n0 + c * CH;
+    if (off < 0 || n >= p.Nout) continue;
+    float v[CH];
+    Chunk<T>::load(reinterpret_cast<const T*>(outs + r * SM::kOutStride + c * 16), v);
+    const size_t g = (size_t)off + n;
+    if (R) { float w[CH]; Chunk<T>::load(R + g, w);
+#pragma unroll
+      for (int e = 0; e < CH; ++e) v[e] += w[e]; }
+    if (p.accumulate) { float w[CH]; Chunk<T>::load(D + g, w);
+#pragma unroll
+      for (int e = 0; e < CH; ++e) v[e] += w[e]; }
+    Chunk<T>::store(D + g, v);
+  }
+}
+
+// ------------------------------------------------------------------------------------ wgrad
+struct WgradArgs {
+  const void* X; const void* DY; float* out;
+  int Hi, Wi, Ci, Ho, Wo, Co;
+  int kw, stride, pad, cshift;
+  int M, rows_per_split, ldw;
+  long slab_stride;
+  int nto, nti;
+  FastDiv dWo, dHo;
+};
+
+// tr16-read friendly swizzle of a [rows][256 B] bf16 image (guide T10, image (b))
+__device__ __forceinline__ int swz256(int r, int ch) { return r * 256 + ((ch ^ (((r & 3) << 2) | ((r >> 2) & 3))) << 4); }
+
+template <typename T>
+__global__ __launch_bounds__(256) void wgrad_gemm_kernel(const WgradArgs p) {
+  constexpr int CH = MmaTraits<T>::CH;
+  constexpr int BKM = (sizeof(T) == 2) ? 64 : 32;   // reduction rows per LDS tile
+  constexpr int CPR = 128 / CH;                      // chunks per 128-wide tile row
+  constexpr int RPT = BKM * CPR / 256;               // rows per thread per operand
+  constexpr int ROWB = 128 * (int)sizeof(T);         // LDS row bytes
+  __shared__ __attribute__((aligned(16))) char smem[2 * BKM * ROWB];
+  char* ys = smem;                 // DY tile [BKM][128 o]
+  char* xs = smem + BKM * ROWB;    // X  tile [BKM][128 cols]
+
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int tile = blockIdx.x;
+  const int o0 = (tile / p.nti) * 128, c0 = (tile % p.nti) * 128;  // c0: flattened (tap, ci) column
+  const int wm0 = (wave >> 1) * 64, wn0 = (wave & 1) * 64;
+  const int lc = t % CPR, lr = t / CPR;
+
+  const T* __restrict__ X = reinterpret_cast<const T*>(p.X);
+  const T* __restrict__ DY = reinterpret_cast<const T*>(p.DY);
+
+  // this thread's fixed column chunk -> (tap, ci)
+  const int col = c0 + lc * CH;
+  const bool colok = col < p.ldw;
+  const int qc = col / CH;
+  const int tap = colok ? (qc >> p.cshift) : 0;
+  const int ci = (qc & ((1 << p.cshift) - 1)) * CH;
+  const int tdy = tap / p.kw - p.pad, tdx = tap % p.kw - p.pad;
+  const bool ook = (o0 + lc * CH) < p.Co;
+
+  const int mbeg = blockIdx.z * p.rows_per_split;
+  const int mend = min(p.M, mbeg + p.rows_per_split);
+
+  uint4 rx[RPT], ry[RPT];
+  auto load_tile = [&](int mt0) {
+#pragma unroll
+    for (int i = 0; i < RPT; ++i) {
+      const int m = mt0 + lr + (256 / CPR) * i;
+      rx[i] = make_uint4(0, 0, 0, 0); ry[i] = make_uint4(0, 0, 0, 0);
+      if (m < mend) {
+        if (ook) ry[i] = *reinterpret_cast<const uint4*>(DY + ((size_t)m * p.Co + o0 + lc * CH));
+        if (colok) {
+          unsigned r = fd_div((unsigned)m, p.dWo); int ox = m - r * p.Wo;
+          unsigned n = fd_div(r, p.dHo); int oy = r - n * p.Ho;
+          int iy = oy * p.stride + tdy, ix = ox * p.stride + tdx;
+          if ((unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi)
+            rx[i] = *reinterpret_cast<const uint4*>(X + (((size_t)n * p.Hi + iy) * p.Wi + ix) * p.Ci + ci);
+        }
+      }
+    }
+  };
+  auto store_tile = [&]() {
+#pragma unroll
+    for (int i = 0; i < RPT; ++i) {
+      const int r = lr + (256 / CPR) * i;
+      int off;
+      if constexpr (sizeof(T) == 2) off = swz256(r, lc); else off = r * ROWB + lc * 16;
+      *reinterpret_cast<uint4*>(ys + off) = ry[i];
+      *reinterpret_cast<uint4*>(xs + off) = rx[i];
+    }
+  };
+
+  f32x16_t acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int r31 = lane & 31, hi = lane >> 5;
+  // tr16 lane roles: 16-lane group g reads a 4-row x 16-col block; lane 4q+p supplies row q, cols 4p..4p+3
+  const int tg = lane >> 4, tq = (lane & 15) >> 2, tp = lane & 3;
+  if (mbeg < mend) load_tile(mbeg);
+  for (int mt0 = mbeg; mt0 < mend; mt0 += BKM) {
+    __syncthreads();   // previous tile's reads done
+    store_tile();
+    __syncthreads();
+    if (mt0 + BKM < mend) load_tile(mt0 + BKM);
+    if constexpr (sizeof(T) == 2) {
+#pragma unroll
+      for (int s = 0; s < BKM / 16; ++s) {
+        bf16x8_t a[2], b[2];
+        const int row = 16 * s + 8 * (tg >> 1) + tq;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const int chA = (wm0 + i * 32) / 8 + 2 * (tg & 1) + (tp >> 1);
+          const int chB = (wn0 + i * 32) / 8 + 2 * (tg & 1) + (tp >> 1);
+          typedef __attribute__((address_space(3))) bf16x4_t* lds4;
+          bf16x4_t a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4)(ys + swz256(row, chA) + 8 * (tp & 1)));
+          bf16x4_t a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4)(ys + swz256(row + 4, chA) + 8 * (tp & 1)));
+          bf16x4_t b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4)(xs + swz256(row, chB) + 8 * (tp & 1)));
+          bf16x4_t b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4)(xs + swz256(row + 4, chB) + 8 * (tp & 1)));
+          a[i] = __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7);
+          b[i] = __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+      }
+    } else {
+#pragma unroll
+      for (int s = 0; s < BKM / 2; ++s) {
+        const int row = 2 * s + hi;
+        float a[2], b[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          a[i] = *reinterpret_cast<const float*>(ys + row * ROWB + (wm0 + i * 32 + r31) * 4);
+          b[i] = *reinterpret_cast<const float*>(xs + row * ROWB + (wn0 + i * 32 + r31) * 4);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+      }
+    }
+  }
+  float* out = p.out + (size_t)blockIdx.z * p.slab_stride;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int o = o0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+        const int c = c0 + wn0 + j * 32 + r31;
+        if (o < p.Co && c < p.ldw) out[(size_t)o * p.ldw + c] = acc[i][j][r];
+      }
+}
+
+__global__ void slab_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ out, long n, int S,
+                                   long stride, int accumulate) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float v = accumulate ? out[i] : 0.f;
+  for (int s = 0; s < S; ++s) v += slabs[(size_t)s * stride + i];
+  out[i] = v;
+}
+
+// ------------------------------------------------------------------------------------ host side
+static int ilog2_exact(int v) { int s = 0; while ((1 << s) < v) ++s; return ((1 << s) == v) ? s : -1; }
+
+template <typename T, int BM, int BN, bool SMALL_C>
+static void launch_gather(GatherArgs& a, hipStream_t st) {
+  a.ntm = cdiv(a.M, BM); a.ntn = cdiv(a.Nout, BN);
+  constexpr int smem = GatherSmem<T, BM, BN>::kBytes;
+  auto kern = gather_gemm_kernel<T, BM, BN, SMALL_C>;
+  static bool attr_set = false;   // raise the dynamic-LDS cap once per instantiation
+  if (!attr_set) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem); attr_set = true; }
+  hipLaunchKernelGGL(kern, dim3(a.ntm * a.ntn), dim3(256), smem, st, a);
+}
+
+template <typename T>
+static int dispatch_gather(GatherArgs& a, hipStream_t st) {
+  constexpr int CH = MmaTraits<T>::CH;
+  if (a.Ci % CH) MI_FAIL(MI355_EINVAL, "gather: Ci=%d not a multiple of %d", a.Ci, CH);
+  a.cshift = ilog2_exact(a.Ci / CH);
+  if (a.cshift < 0) MI_FAIL(MI355_EINVAL, "gather: Ci/%d must be a power of two (Ci=%d)", CH, a.Ci);
+  if (a.Nout % CH) MI_FAIL(MI355_EINVAL, "gather: Nout=%d not a multiple of %d", a.Nout, CH);
+  a.kchunks = a.ntaps << a.cshift;
+  const bool small = (a.Ci / CH) < 8;
+  double flops = 2.0 * a.M * (double)a.Nout * a.ntaps * a.Ci;
+  ProfScope ps(st, flops);
+  if (small) { launch_gather<T, 128, 64, true>(a, st); }
+  else {
+    const long t128 = (long)cdiv(a.M, 128) * cdiv(a.Nout, 128);
+    if (a.Nout <= 64) {
+      if ((long)cdiv(a.M, 128) >= 512) launch_gather<T, 128, 64, false>(a, st); else launch_gather<T, 64, 64, false>(a, st);
+    } else if (t128 >= 512) launch_gather<T, 128, 128, false>(a, st);
+    else if ((long)cdiv(a.M, 64) * cdiv(a.Nout, 128) >= 512) launch_gather<T, 64, 128, false>(a, st);
+    else launch_gather<T, 64, 64, false>(a, st);
+  }
+  MI_CHECK_LAUNCH("gather_gemm");
+  return MI355_OK;
+}
+
+static int check_desc(const mi355_conv_desc* d) {
+  if (!d) MI_FAIL(MI355_EINVAL, "null conv desc");
+  if (d->dtype != MI355_F32 && d->dtype != MI355_BF16) MI_FAIL(MI355_EINVAL, "bad dtype %d", d->dtype);
+  if (d->kh * d->kw > MAX_TAPS || d->kh < 1 || d->kw < 1) MI_FAIL(MI355_EINVAL, "unsupported kernel %dx%d", d->kh, d->kw);
+  if (d->stride < 1 || d->stride > 2) MI_FAIL(MI355_EINVAL, "unsupported stride %d", d->stride);
+  if (d->Ho != (d->Hi + 2 * d->pad - d->kh) / d->stride + 1 || d->Wo != (d->Wi + 2 * d->pad - d->kw) / d->stride + 1)
+    MI_FAIL(MI355_EINVAL, "conv desc: output size %dx%d inconsistent with input %dx%d k%d s%d p%d", d->Ho, d->Wo, d->Hi, d->Wi, d->kh, d->stride, d->pad);
+  if ((long)d->N * d->Hi * d->Wi * d->Ci >= (1L << 31) || (long)d->N * d->Ho * d->Wo * d->Co >= (1L << 31))
+    MI_FAIL(MI355_EINVAL, "tensor too large for 32-bit element offsets");
+  return MI355_OK;
+}
+
+extern "C" int mi355_conv_fwd(const mi355_conv_desc* d, const void* x, const void* w, const float* bias,
+                              const void* residual, void* y, void* stream) {
+  if (int e = check_desc(d)) return e;
+  GatherArgs a; memset(&a, 0, sizeof(a));
+  a.A = x; a.B = w; a.D = y; a.bias = bias; a.residual = residual; a.scale = nullptr;
+  a.Hi = d->Hi; a.Wi = d->Wi; a.Ci = d->Ci; a.OHp = d->Ho; a.OWp = d->Wo; a.in_sy = a.in_sx = d->stride;
+  a.Ho = d->Ho; a.Wo = d->Wo; a.out_sy = a.out_sx = 1; a.out_oy = a.out_ox = 0;
+  a.Nout = d->Co; a.ldd = d->Co; a.ldb = d->kh * d->kw * d->Ci; a.M = d->N * d->Ho * d->Wo; a.accumulate = 0;
+  a.ntaps = d->kh * d->kw;
+  for (int i = 0; i < d->kh; ++i)
+    for (int j = 0; j < d->kw; ++j) { Tap& t = a.taps[i * d->kw + j]; t.dy = (int8_t)(i - d->pad); t.dx = (int8_t)(j - d->pad); t.widx = (int16_t)(i * d->kw + j); }
+  return d->dtype == MI355_BF16 ? dispatch_gather<bf16_t>(a, as_stream(stream)) : dispatch_gather<float>(a, as_stream(stream));
+}
+
+// conv-form dgrad: dx[n][iy][ix][ci] = sum_{kh,kw,co} dy[n][(iy+p-kh)/s][(ix+p-kw)/s][co] * w[co][kh][kw][ci]
+// decomposed into stride^2 phases (iy%s, ix%s), each a unit-stride gather over its own tap subset.
+extern "C" int mi355_conv_dgrad(const mi355_conv_desc* d, const void* dy, const void* wT, const float* bias,
+                                const float* scale_dev, int accumulate, void* dx, void* stream) {
+  if (int e = check_desc(d)) return e;
+  hipStream_t st = as_stream(stream);
+  const int s = d->stride;
+  const size_t esz = d->dtype == MI355_BF16 ? 2 : 4;
+  bool need_zero = false;
+  for (int py = 0; py < s && !need_zero; ++py) {
+    int cnt = 0; for (int kh = 0; kh < d->kh; ++kh) if ((py + d->pad - kh) % s == 0) ++cnt;
+    if (!cnt) need_zero = true;
+  }
+  for (int px = 0; px < s && !need_zero; ++px) {
+    int cnt = 0; for (int kw = 0; kw < d->kw; ++kw) if ((px + d->pad - kw) % s == 0) ++cnt;
+    if (!cnt) need_zero = true;
+  }
+  if (need_zero && !accumulate) {
+    if (hipMemsetAsync(dx, 0, (size_t)d->N * d->Hi * d->Wi * d->Ci * esz, st) != hipSuccess) MI_FAIL(MI355_ELAUNCH, "memset failed");
+  }
+  for (int py = 0; py < s; ++py)
+    for (int px = 0; px < s; ++px) {
+      GatherArgs a; memset(&a, 0, sizeof(a));
+      a.A = dy; a.B = wT; a.D = dx; a.bias = bias; a.residual = nullptr; a.scale = scale_dev;
+      a.Hi = d->Ho; a.Wi = d->Wo; a.Ci = d->Co;
+      a.OHp = (d->Hi - py + s - 1) / s; a.OWp = (d->Wi - px + s - 1) / s;
+      if (a.OHp <= 0 || a.OWp <= 0) continue;
+      a.in_sy = a.in_sx = 1; a.Ho = d->Hi; a.Wo = d->Wi; a.out_sy = a.out_sx = s; a.out_oy = py; a.out_ox = px;
+      a.Nout = d->Ci; a.ldd = d->Ci; a.ldb = d->kh * d->kw * d->Co; a.M = d->N * a.OHp * a.OWp;
+      a.accumulate = accumulate ? 1 : 0;
+      int nt = 0;
+      for (int kh = 0; kh < d->kh; ++kh) {
+        if ((py + d->pad - kh) % s != 0) continue;
+        for (int kw = 0; kw < d->kw; ++kw) {
+          if ((px + d->pad - kw) % s != 0) continue;
+          Tap& t = a.taps[nt++]; t.dy = (int8_t)((py + d->pad - kh) / s); t.dx = (int8_t)((px + d->pad - kw) / s);
+          t.widx = (int16_t)(kh * d->kw + kw);
+        }
+      }
+      if (nt == 0) continue;   // region already zeroed (or left untouched when accumulating)
+      a.ntaps = nt;
+      int e = d->dtype == MI355_BF16 ? dispatch_gather<bf16_t>(a, st) : dispatch_gather<float>(a, st);
+      if (e) return e;
+    }
+  return MI355_OK;
+}
+
+struct WgradPlan { int S, rows_per_split, nto, nti, ldw; };
+static WgradPlan plan_wgrad(const mi355_conv_desc* d) {
+  WgradPlan w; w.ldw = d->kh * d->kw * d->Ci;
+  w.nto = cdiv(d->Co, 128); w.nti = cdiv(w.ldw, 128);
+  const int bkm = d->dtype == MI355_BF16 ? 64 : 32;
+  const long M = (long)d->N * d->Ho * d->Wo;
+  long tiles = (long)w.nto * w.nti;
+  long S = (768 + tiles - 1) / tiles;
+  long maxS = (M + 4 * bkm - 1) / (4 * bkm);
+  if (S > maxS) S = maxS;
+  if (S < 1) S = 1;
+  long rps = (M + S - 1) / S; rps = ((rps + bkm - 1) / bkm) * bkm;
+  S = (M + rps - 1) / rps;
+  w.S = (int)S; w.rows_per_split = (int)rps;
+  return w;
+}
+
+extern "C" size_t mi355_conv_wgrad_workspace(const mi355_conv_desc* d) {
+  WgradPlan w = plan_wgrad(d);
+  return (size_t)w.S * d->Co * w.ldw * sizeof(float);
+}
+
+extern "C" int mi355_conv_wgrad(const mi355_conv_desc* d, const void* x, const void* dy, float* dw, int accumulate,
+                                void* ws, size_t ws_bytes, void* stream) {
+  if (int e = check_desc(d)) return e;
+  hipStream_t st = as_stream(stream);
+  const int CH = d->dtype == MI355_BF16 ? 8 : 4;
+  if (d->Ci % CH || d->Co % CH) MI_FAIL(MI355_EINVAL, "wgrad: channels must be multiples of %d", CH);
+  int cshift = ilog2_exact(d->Ci / CH);
+  if (cshift < 0) MI_FAIL(MI355_EINVAL, "wgrad: Ci/%d must be a power of two", CH);
+  WgradPlan w = plan_wgrad(d);
+  const size_t need = (size_t)w.S * d->Co * w.ldw * sizeof(float);
+  const bool direct = (w.S == 1 && !accumulate);
+  if (!direct && (ws == nullptr || ws_bytes < need)) MI_FAIL(MI355_EWORKSPACE, "wgrad workspace %zu < %zu", ws_bytes, need);
+  WgradArgs a; memset(&a, 0, sizeof(a));
+  a.X = x; a.DY = dy; a.out = direct ? dw : reinterpret_cast<float*>(ws);
+  a.Hi = d->Hi; a.Wi = d->Wi; a.Ci = d->Ci; a.Ho = d->Ho; a.Wo = d->Wo; a.Co = d->Co;
+  a.kw = d->kw; a.stride = d->stride; a.pad = d->pad; a.cshift = cshift;
+  a.M = d->N * d->Ho * d->Wo; a.rows_per_split = w.rows_per_split; a.ldw = w.ldw;
+  a.slab_stride = (long)d->Co * w.ldw; a.nto = w.nto; a.nti = w.nti;
+  a.dWo = make_fastdiv(d->Wo); a.dHo = make_fastdiv(d->Ho);
+  {
+    ProfScope ps(st, 2.0 * a.M * (double)d->Co * w.ldw);
+    dim3 grid(w.nto * w.nti, 1, w.S);
+    if (d->dtype == MI355_BF16) hipLaunchKernelGGL(wgrad_gemm_kernel<bf16_t>, grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(wgrad_gemm_kernel<float>, grid, dim3(256), 0, st, a);
+    MI_CHECK_LAUNCH("wgrad_gemm");
+  }
+  if (!direct) {
+    long n = a.slab_stride;
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, reinterpret_cast<const float*>(ws), dw, n, w.S, a.slab_stride, accumulate);
+    MI_CHECK_LAUNCH("slab_reduce");
+  }
+  return MI355_OK;
+}
+
+// ------------------------------------------------------------------------------------ weight packing
+template <typename T>
+__global__ void pack_weights_kernel(const float* __restrict__ w, T* __restrict__ wf, T* __restrict__ wt, int O, int Tt, int I, int Ipad) {
+  // tile 32(o) x 32(i) per tap through LDS so both the read ([O][T][I]) and the transposed write ([Ipad][T][O]) coalesce;
+  // channels I..Ipad-1 of the packed copies are zero (stem: 3 -> 8)
+  __shared__ float tile[32][33];
+  const int tap = blockIdx.z, o0 = blockIdx.y * 32, i0 = blockIdx.x * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  for (int r = ty; r < 32; r += 8) {
+    int o = o0 + r, i = i0 + tx;
+    float v = (o < O && i < I) ? w[((size_t)o * Tt + tap) * I + i] : 0.f;
+    tile[r][tx] = v;
+    if (wf && o < O && i < Ipad) Elem<T>::st(wf + ((size_t)o * Tt + tap) * Ipad + i, v);
+  }
+  __syncthreads();
+  if (wt)
+    for (int r = ty; r < 32; r += 8) {
+      int i = i0 + r, o = o0 + tx;
+      if (o < O && i < Ipad) Elem<T>::st(wt + ((size_t)i * Tt + tap) * O + o, tile[tx][r]);
+    }
+}
+
+extern "C" int mi355_pack_weights(const float* w, void* wf, void* wt, int O, int Tt, int I, int Ipad, int dtype, void* stream) {
+  if (!w || O < 1 || Tt < 1 || I < 1 || Ipad < I) MI_FAIL(MI355_EINVAL, "pack_weights: bad args");
+  dim3 grid(cdiv(Ipad, 32), cdiv(O, 32), Tt);
+  if (dtype == MI355_BF16) hipLaunchKernelGGL(pack_weights_kernel<bf16_t>, grid, dim3(256), 0, as_stream(stream), w, (bf16_t*)wf, (bf16_t*)wt, O, Tt, I, Ipad);
+  else if (dtype == MI355_F32) hipLaunchKernelGGL(pack_weights_kernel<float>, grid, dim3(256), 0, as_stream(stream), w, (float*)wf, (float*)wt, O, Tt, I, Ipad);
+  else MI_FAIL(MI355_EINVAL, "bad dtype");
+  MI_CHECK_LAUNCH("pack_weights");
+  return MI355_OK;
+}

@@ -1,0 +1,138 @@
+// Stem max-pool 3x3 s2 p1 (NHWC, argmax kept as a window-position byte) and the NCHW<->NHWC edge
+// conversions.  HBM-bound; 16-byte chunks per lane.
+#include "common.h"
+
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, uint8_t* __restrict__ arg,
+                                                           int N, int H, int W, int C, int Ho, int Wo) {
+  constexpr int CH = Chunk<T>::N;
+  const int cpr = C / CH;
+  const long total = (long)N * Ho * Wo * cpr;
+  for (long id = (long)blockIdx.x * 256 + threadIdx.x; id < total; id += (long)gridDim.x * 256) {
+    const int ch = (int)(id % cpr); long r = id / cpr;
+    const int ox = (int)(r % Wo); r /= Wo; const int oy = (int)(r % Ho); const int n = (int)(r / Ho);
+    float best[CH]; int bi[CH]; bool first = true;
+#pragma unroll
+    for (int e = 0; e < CH; ++e) { best[e] = -INFINITY; bi[e] = 0; }
+    for (int kh = 0; kh < 3; ++kh) {
+      const int iy = 2 * oy - 1 + kh; if (iy < 0 || iy >= H) continue;
+      for (int kw = 0; kw < 3; ++kw) {
+        const int ix = 2 * ox - 1 + kw; if (ix < 0 || ix >= W) continue;
+        float v[CH]; Chunk<T>::load(x + (((size_t)n * H + iy) * W + ix) * C + (size_t)ch * CH, v);
+        const int code = kh * 3 + kw;
+#pragma unroll
+        for (int e = 0; e < CH; ++e) {
+          if (first) bi[e] = code;                       // ATen: index starts at the first valid position
+          if (v[e] > best[e] || v[e] != v[e]) { best[e] = v[e]; bi[e] = code; }
+        }
+        first = false;
+      }
+    }
+    const size_t o = (((size_t)n * Ho + oy) * Wo + ox) * C + (size_t)ch * CH;
+    Chunk<T>::store(y + o, best);
+#pragma unroll
+    for (int e = 0; e < CH; ++e) arg[o + e] = (uint8_t)bi[e];
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T* __restrict__ dy, const uint8_t* __restrict__ arg, T* __restrict__ dx,
+                                                           int N, int H, int W, int C, int Ho, int Wo) {
+  constexpr int CH = Chunk<T>::N;
+  const int cpr = C / CH;
+  const long total = (long)N * H * W * cpr;
+  for (long id = (long)blockIdx.x * 256 + threadIdx.x; id < total; id += (long)gridDim.x * 256) {
+    const int ch = (int)(id % cpr); long r = id / cpr;
+    const int ix = (int)(r % W); r /= W; const int iy = (int)(r % H); const int n = (int)(r / H);
+    float g[CH];
+#pragma unroll
+    for (int e = 0; e < CH; ++e) g[e] = 0.f;
+    for (int kh = 0; kh < 3; ++kh) {
+      const int ty = iy + 1 - kh; if (ty < 0 || (ty & 1)) continue; const int oy = ty >> 1; if (oy >= Ho) continue;
+      for (int kw = 0; kw < 3; ++kw) {
+        const int tx = ix + 1 - kw; if (tx < 0 || (tx & 1)) continue; const int ox = tx >> 1; if (ox >= Wo) continue;
+        const size_t o = (((size_t)n * Ho + oy) * Wo + ox) * C + (size_t)ch * CH;
+        float d[CH]; Chunk<T>::load(dy + o, d);
+        const int code = kh * 3 + kw;
+#pragma unroll
+        for (int e = 0; e < CH; ++e) if (arg[o + e] == code) g[e] += d[e];
+      }
+    }
+    Chunk<T>::store(dx + (((size_t)n * H + iy) * W + ix) * C + (size_t)ch * CH, g);
+  }
+}
+
+extern "C" int mi355_maxpool_fwd(const void* x, void* y, uint8_t* argidx, int N, int H, int W, int C, int dtype, void* stream) {
+  const int CH = dtype == MI355_BF16 ? 8 : 4;
+  if (C % CH || N < 1 || !argidx) MI_FAIL(MI355_EINVAL, "maxpool_fwd: bad args (C=%d)", C);
+  const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+  long total = (long)N * Ho * Wo * (C / CH);
+  int grid = (int)((total + 255) / 256); if (grid > 8192) grid = 8192;
+  if (dtype == MI355_BF16) hipLaunchKernelGGL(maxpool_fwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, as_stream(stream), (const bf16_t*)x, (bf16_t*)y, argidx, N, H, W, C, Ho, Wo);
+  else hipLaunchKernelGGL(maxpool_fwd_kernel<float>, dim3(grid), dim3(256), 0, as_stream(stream), (const float*)x, (float*)y, argidx, N, H, W, C, Ho, Wo);
+  MI_CHECK_LAUNCH("maxpool_fwd");
+  return MI355_OK;
+}
+
+extern "C" int mi355_maxpool_bwd(const void* dy, const uint8_t* argidx, void* dx, int N, int H, int W, int C, int dtype, void* stream) {
+  const int CH = dtype == MI355_BF16 ? 8 : 4;
+  if (C % CH || N < 1 || !argidx) MI_FAIL(MI355_EINVAL, "maxpool_bwd: bad args (C=%d)", C);
+  const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+  long total = (long)N * H * W * (C / CH);
+  int grid = (int)((total + 255) / 256); if (grid > 8192) grid = 8192;
+  if (dtype == MI355_BF16) hipLaunchKernelGGL(maxpool_bwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, as_stream(stream), (const bf16_t*)dy, argidx, (bf16_t*)dx, N, H, W, C, Ho, Wo);
+  else hipLaunchKernelGGL(maxpool_bwd_kernel<float>, dim3(grid), dim3(256), 0, as_stream(stream), (const float*)dy, argidx, (float*)dx, N, H, W, C, Ho, Wo);
+  MI_CHECK_LAUNCH("maxpool_bwd");
+  return MI355_OK;
+}
+
+// ---------------------------------------------------------------- NCHW fp32 -> NHWC T (zero-padded channels)
+template <typename T>
+__global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restrict__ x, T* __restrict__ y, int N, int C, int HW, int Cpad) {
+  constexpr int CH = Chunk<T>::N;
+  const int cpr = Cpad / CH;
+  const long total = (long)N * HW * cpr;
+  for (long id = (long)blockIdx.x * 256 + threadIdx.x; id < total; id += (long)gridDim.x * 256) {
+    // pixel fastest so the strided NCHW reads coalesce across lanes
+    const int p = (int)(id % HW); long r = id / HW; const int ch = (int)(r % cpr); const int n = (int)(r / cpr);
+    float v[CH];
+#pragma unroll
+    for (int e = 0; e < CH; ++e) { const int c = ch * CH + e; v[e] = c < C ? x[((size_t)n * C + c) * HW + p] : 0.f; }
+    Chunk<T>::store(y + ((size_t)n * HW + p) * Cpad + (size_t)ch * CH, v);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const T* __restrict__ x, float* __restrict__ y, int N, int C, int HW) {
+  __shared__ float tile[32][33];
+  const int n = blockIdx.z, p0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int r = ty; r < 32; r += 8) {
+    const int p = p0 + r, c = c0 + tx;
+    tile[r][tx] = (p < HW && c < C) ? Elem<T>::ld(x + ((size_t)n * HW + p) * C + c) : 0.f;
+  }
+  __syncthreads();
+  for (int r = ty; r < 32; r += 8) {
+    const int c = c0 + r, p = p0 + tx;
+    if (p < HW && c < C) y[((size_t)n * C + c) * HW + p] = tile[tx][r];
+  }
+}
+
+extern "C" int mi355_nchw_to_nhwc(const float* x, void* y, int N, int C, int H, int W, int Cpad, int dtype, void* stream) {
+  const int CH = dtype == MI355_BF16 ? 8 : 4;
+  if (Cpad % CH || Cpad < C) MI_FAIL(MI355_EINVAL, "nchw_to_nhwc: Cpad=%d must be a multiple of %d and >= C=%d", Cpad, CH, C);
+  long total = (long)N * H * W * (Cpad / CH);
+  int grid = (int)((total + 255) / 256); if (grid > 16384) grid = 16384;
+  if (dtype == MI355_BF16) hipLaunchKernelGGL(nchw_to_nhwc_kernel<bf16_t>, dim3(grid), dim3(256), 0, as_stream(stream), x, (bf16_t*)y, N, C, H * W, Cpad);
+  else hipLaunchKernelGGL(nchw_to_nhwc_kernel<float>, dim3(grid), dim3(256), 0, as_stream(stream), x, (float*)y, N, C, H * W, Cpad);
+  MI_CHECK_LAUNCH("nchw_to_nhwc");
+  return MI355_OK;
+}
+
+extern "C" int mi355_nhwc_to_nchw(const void* x, float* y, int N, int C, int H, int W, int dtype, void* stream) {
+  dim3 grid(cdiv(H * W, 32), cdiv(C, 32), N);
+  if (dtype == MI355_BF16) hipLaunchKernelGGL(nhwc_to_nchw_kernel<bf16_t>, grid, dim3(256), 0, as_stream(stream), (const bf16_t*)x, y, N, C, H * W);
+  else hipLaunchKernelGGL(nhwc_to_nchw_kernel<float>, grid, dim3(256), 0, as_stream(stream), (const float*)x, y, N, C, H * W);
+  MI_CHECK_LAUNCH("nhwc_to_nchw");
+  return MI355_OK;
+}

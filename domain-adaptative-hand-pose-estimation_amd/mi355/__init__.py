@@ -1,0 +1,149 @@
+"""ctypes binding of libmi355pose.so (include/mi355pose.h).
+
+The product path has NO CPU / PyTorch fallback: every op raises if the HIP library is missing or a
+call fails.  PyTorch is used for device memory, streams and autograd bookkeeping only.
+"""
+import ctypes
+import os
+import threading
+
+import torch
+
+F32, BF16 = 0, 1
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), 'libmi355pose.so')
+
+_lib = None
+_lock = threading.Lock()
+
+
+class Mi355Error(RuntimeError):
+    pass
+
+
+class ConvDesc(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int) for n in
+                ('N', 'Hi', 'Wi', 'Ci', 'Ho', 'Wo', 'Co', 'kh', 'kw', 'stride', 'pad', 'dtype')]
+
+
+# name -> (restype, argtypes); mirrors include/mi355pose.h one to one
+_P, _I, _L, _F, _Z = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_float, ctypes.c_size_t
+_D = ctypes.POINTER(ConvDesc)
+SIGNATURES = {
+    'mi355_version': (_I, []),
+    'mi355_last_error': (ctypes.c_char_p, []),
+    'mi355_conv_fwd': (_I, [_D, _P, _P, _P, _P, _P, _P]),
+    'mi355_conv_dgrad': (_I, [_D, _P, _P, _P, _P, _I, _P, _P]),
+    'mi355_conv_wgrad_workspace': (_Z, [_D]),
+    'mi355_conv_wgrad': (_I, [_D, _P, _P, _P, _I, _P, _Z, _P]),
+    'mi355_pack_weights': (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    'mi355_colsum_workspace': (_Z, [_L, _I]),
+    'mi355_colsum': (_I, [_P, _P, _L, _I, _I, _I, _P, _Z, _P]),
+    'mi355_bn_workspace': (_Z, [_L, _I]),
+    'mi355_bn_train_fwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _F, _F, _I, _I, _P, _Z, _P]),
+    'mi355_bn_eval_fwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _L, _I, _F, _I, _I, _P]),
+    'mi355_bn_bwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _L, _I, _I, _I, _P, _Z, _P]),
+    'mi355_maxpool_fwd': (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    'mi355_maxpool_bwd': (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    'mi355_nchw_to_nhwc': (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    'mi355_nhwc_to_nchw': (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
+    'mi355_pw_c2k': (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    'mi355_pw_k2c': (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    'mi355_pw_wgrad_workspace': (_Z, [_I, _I, _I, _I]),
+    'mi355_pw_wgrad': (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _Z, _P]),
+    'mi355_hm_rowsum': (_I, [_P, _P, _I, _I, _I, _I, _P, _Z, _P]),
+    'mi355_argmax2d': (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),
+    'mi355_softargmax': (_I, [_P, _P, _I, _I, _I, _F, _F, _P]),
+    'mi355_kl_heatmap': (_I, [_P, _P, _P, _F, _P, _P, _I, _I, _F, _P]),
+    'mi355_reduce_sum': (_I, [_P, _P, _I, _F, _P]),
+    'mi355_scale_by_dev': (_I, [_P, _P, _P, _L, _P]),
+    'mi355_pseudo_label': (_I, [_P, _P, _I, _I, _I, _I, _P, _I, _P, _P, _I, _I, _P]),
+    'mi355_bilinear_up': (_I, [_P, _P, _I, _I, _I, _I, _I, _F, _I, _P]),
+    'mi355_pck_dists': (_I, [_P, _P, _P, _I, _F, _F, _P]),
+    'mi355_sgd_nesterov': (_I, [_P, _P, _P, _L, _P, _F, _F, _I, _P, _P]),
+    'mi355_cast_f32': (_I, [_P, _P, _L, _I, _P]),
+    'mi355_prof_enable': (_I, [_I]),
+    'mi355_prof_reset': (_I, []),
+    'mi355_prof_read': (_I, [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_long),
+                             ctypes.POINTER(ctypes.c_double)]),
+}
+
+
+def load(path=None):
+    """Load the shared library (once).  Raises Mi355Error when it is missing: there is no fallback."""
+    global _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        path = path or LIB_PATH
+        if not os.path.exists(path):
+            raise Mi355Error(
+                'libmi355pose.so not found at %s: build it with '
+                '`python domain-adaptative-hand-pose-estimation_amd/build.py` (hipcc, gfx950). '
+                'The MI355X path has no CPU fallback.' % path)
+        lib = ctypes.CDLL(path)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype, fn.argtypes = res, args
+        _lib = lib
+        return lib
+
+
+def call(name, *args):
+    lib = load()
+    rc = getattr(lib, name)(*args)
+    if rc != 0:
+        raise Mi355Error('%s failed (%d): %s' % (name, rc, lib.mi355_last_error().decode()))
+
+
+def stream_ptr():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def ptr(t):
+    return 0 if t is None else t.data_ptr()
+
+
+# ---------------------------------------------------------------- compute dtype (activations + packed weights)
+_compute_dtype = torch.bfloat16
+
+
+def set_compute_dtype(dt):
+    """'bf16' (default, throughput path) or 'f32' (exact-fp32 MFMA parity path)."""
+    global _compute_dtype
+    if dt in ('bf16', torch.bfloat16):
+        _compute_dtype = torch.bfloat16
+    elif dt in ('f32', 'fp32', torch.float32):
+        _compute_dtype = torch.float32
+    else:
+        raise ValueError('compute dtype must be bf16 or f32, got %r' % (dt,))
+
+
+def compute_dtype():
+    return _compute_dtype
+
+
+def dtype_code(dt):
+    if dt == torch.bfloat16:
+        return BF16
+    if dt == torch.float32:
+        return F32
+    raise Mi355Error('unsupported dtype %s' % dt)
+
+
+# ---------------------------------------------------------------- shared scratch (stream-ordered reuse)
+_ws = {}
+
+
+def workspace(nbytes, device):
+    """One grow-only scratch buffer per device; all ops are enqueued on the current stream, so reuse is
+    ordered.  Grows outside graph capture only (warm up before capturing)."""
+    key = (device.index if device.index is not None else torch.cuda.current_device())
+    buf = _ws.get(key)
+    if buf is None or buf.numel() < nbytes:
+        if torch.cuda.is_current_stream_capturing():
+            raise Mi355Error('workspace would grow (%d bytes) during graph capture: warm up first' % nbytes)
+        size = max(int(nbytes), 64 << 20)
+        buf = torch.empty(size, dtype=torch.uint8, device=device)
+        _ws[key] = buf
+    return buf

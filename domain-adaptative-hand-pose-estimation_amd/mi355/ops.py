@@ -1,0 +1,306 @@
+"""Thin tensor-level wrappers over the C ABI (one per entry point of include/mi355pose.h).
+
+Tensors are torch CUDA tensors used as device-memory handles.  Feature maps are *logical* NCHW
+tensors in channels_last memory (= the NHWC layout the kernels use), dtype bf16 or fp32; heat-maps
+are contiguous NCHW fp32.  Nothing here falls back to torch math.
+"""
+import ctypes
+
+import torch
+
+from . import (ConvDesc, Mi355Error, call, compute_dtype, dtype_code, load, ptr, stream_ptr, workspace)
+
+
+# ---------------------------------------------------------------- layout helpers
+def nhwc_empty(N, C, H, W, dtype, device):
+    return torch.empty((N, H, W, C), dtype=dtype, device=device).permute(0, 3, 1, 2)
+
+
+def is_nhwc(x):
+    return x.dim() == 4 and x.permute(0, 2, 3, 1).is_contiguous()
+
+
+def _chk_dev(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise Mi355Error('mi355 ops need CUDA/HIP tensors (got a %s tensor); there is no CPU fallback' % t.device)
+
+
+def to_nhwc(x, dtype=None, cpad=None):
+    """NCHW fp32 (contiguous) -> channels_last `dtype`, channels zero-padded to `cpad`."""
+    dtype = dtype or compute_dtype()
+    N, C, H, W = x.shape
+    per = 8 if dtype == torch.bfloat16 else 4
+    cpad = cpad or ((C + per - 1) // per) * per
+    if is_nhwc(x) and x.dtype == dtype and C == cpad:
+        return x
+    _chk_dev(x)
+    if x.dtype != torch.float32 or not x.is_contiguous():
+        x = x.float().contiguous()
+    y = nhwc_empty(N, cpad, H, W, dtype, x.device)
+    call('mi355_nchw_to_nhwc', ptr(x), ptr(y), N, C, H, W, cpad, dtype_code(dtype), stream_ptr())
+    return y
+
+
+def to_nchw_f32(x):
+    """channels_last bf16/fp32 -> contiguous NCHW fp32."""
+    if not is_nhwc(x):
+        raise Mi355Error('to_nchw_f32 expects a channels_last tensor')
+    _chk_dev(x)
+    N, C, H, W = x.shape
+    y = torch.empty((N, C, H, W), dtype=torch.float32, device=x.device)
+    call('mi355_nhwc_to_nchw', ptr(x), ptr(y), N, C, H, W, dtype_code(x.dtype), stream_ptr())
+    return y
+
+
+def make_desc(N, Hi, Wi, Ci, Co, kh, kw, stride, pad, dtype):
+    Ho = (Hi + 2 * pad - kh) // stride + 1
+    Wo = (Wi + 2 * pad - kw) // stride + 1
+    return ConvDesc(N, Hi, Wi, Ci, Ho, Wo, Co, kh, kw, stride, pad, dtype_code(dtype))
+
+
+# ---------------------------------------------------------------- convolution family
+def conv_fwd(desc, x, w, bias=None, residual=None):
+    _chk_dev(x, w)
+    y = nhwc_empty(desc.N, desc.Co, desc.Ho, desc.Wo, x.dtype, x.device)
+    call('mi355_conv_fwd', ctypes.byref(desc), ptr(x), ptr(w), ptr(bias), ptr(residual), ptr(y), stream_ptr())
+    return y
+
+
+def conv_dgrad(desc, dy, wT, scale_dev=None, out=None, accumulate=False):
+    _chk_dev(dy, wT)
+    dx = out if out is not None else nhwc_empty(desc.N, desc.Ci, desc.Hi, desc.Wi, dy.dtype, dy.device)
+    call('mi355_conv_dgrad', ctypes.byref(desc), ptr(dy), ptr(wT), 0, ptr(scale_dev), int(accumulate), ptr(dx),
+         stream_ptr())
+    return dx
+
+
+def conv_wgrad(desc, x, dy, dw, accumulate):
+    """dw: fp32 buffer in [Co][kh][kw][Ci] memory order (Ci = desc.Ci, i.e. padded for the stem)."""
+    _chk_dev(x, dy, dw)
+    need = load().mi355_conv_wgrad_workspace(ctypes.byref(desc))
+    ws = workspace(need, x.device)
+    call('mi355_conv_wgrad', ctypes.byref(desc), ptr(x), ptr(dy), ptr(dw), int(accumulate), ptr(ws), ws.numel(),
+         stream_ptr())
+
+
+def pack_weights(w_master, O, T, I, Ipad, dtype, want_f=True, want_t=True):
+    """fp32 master in [O][T][I] memory order -> (wf [O][T][Ipad], wt [Ipad][T][O]) in `dtype`."""
+    _chk_dev(w_master)
+    dev = w_master.device
+    wf = torch.empty(O * T * Ipad, dtype=dtype, device=dev) if want_f else None
+    wt = torch.empty(Ipad * T * O, dtype=dtype, device=dev) if want_t else None
+    call('mi355_pack_weights', ptr(w_master), ptr(wf), ptr(wt), O, T, I, Ipad, dtype_code(dtype), stream_ptr())
+    return wf, wt
+
+
+def pack_weights_into(w_master, wf, wt, O, T, I, Ipad, dtype):
+    call('mi355_pack_weights', ptr(w_master), ptr(wf), ptr(wt), O, T, I, Ipad, dtype_code(dtype), stream_ptr())
+
+
+def colsum(dy, out, accumulate):
+    """out[C] (=|+=) column sums of the channels_last tensor dy."""
+    N, C, H, W = dy.shape
+    rows = N * H * W
+    ws = workspace(load().mi355_colsum_workspace(rows, C), dy.device)
+    call('mi355_colsum', ptr(dy), ptr(out), rows, C, dtype_code(dy.dtype), int(accumulate), ptr(ws), ws.numel(),
+         stream_ptr())
+
+
+# ---------------------------------------------------------------- batch norm
+def bn_train_fwd(x, residual, gamma, beta, running_mean, running_var, nbt, eps, momentum, relu):
+    _chk_dev(x, gamma)
+    N, C, H, W = x.shape
+    rows = N * H * W
+    y = nhwc_empty(N, C, H, W, x.dtype, x.device)
+    mean = torch.empty(C, dtype=torch.float32, device=x.device)
+    invstd = torch.empty(C, dtype=torch.float32, device=x.device)
+    ws = workspace(load().mi355_bn_workspace(rows, C), x.device)
+    call('mi355_bn_train_fwd', ptr(x), ptr(residual), ptr(y), ptr(gamma), ptr(beta), ptr(running_mean),
+         ptr(running_var), ptr(nbt), ptr(mean), ptr(invstd), rows, C, float(eps), float(momentum), int(relu),
+         dtype_code(x.dtype), ptr(ws), ws.numel(), stream_ptr())
+    return y, mean, invstd
+
+
+def bn_eval_fwd(x, residual, gamma, beta, running_mean, running_var, eps, relu):
+    _chk_dev(x, gamma)
+    N, C, H, W = x.shape
+    y = nhwc_empty(N, C, H, W, x.dtype, x.device)
+    call('mi355_bn_eval_fwd', ptr(x), ptr(residual), ptr(y), ptr(gamma), ptr(beta), ptr(running_mean),
+         ptr(running_var), N * H * W, C, float(eps), int(relu), dtype_code(x.dtype), stream_ptr())
+    return y
+
+
+def bn_bwd(dy, x, y, gamma, mean, invstd, dgamma, dbeta, accumulate, relu, want_dres):
+    N, C, H, W = x.shape
+    rows = N * H * W
+    dx = nhwc_empty(N, C, H, W, x.dtype, x.device)
+    dres = nhwc_empty(N, C, H, W, x.dtype, x.device) if want_dres else None
+    ws = workspace(load().mi355_bn_workspace(rows, C), x.device)
+    call('mi355_bn_bwd', ptr(dy), ptr(x), ptr(y), ptr(gamma), ptr(mean), ptr(invstd), ptr(dx), ptr(dres),
+         ptr(dgamma), ptr(dbeta), int(accumulate), rows, C, int(relu), dtype_code(x.dtype), ptr(ws), ws.numel(),
+         stream_ptr())
+    return dx, dres
+
+
+# ---------------------------------------------------------------- max pool
+def maxpool_fwd(x):
+    N, C, H, W = x.shape
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    y = nhwc_empty(N, C, Ho, Wo, x.dtype, x.device)
+    arg = torch.empty((N, Ho, Wo, C), dtype=torch.uint8, device=x.device)
+    call('mi355_maxpool_fwd', ptr(x), ptr(y), ptr(arg), N, H, W, C, dtype_code(x.dtype), stream_ptr())
+    return y, arg
+
+
+def maxpool_bwd(dy, arg, in_shape):
+    N, C, H, W = in_shape
+    dx = nhwc_empty(N, C, H, W, dy.dtype, dy.device)
+    call('mi355_maxpool_bwd', ptr(dy), ptr(arg), ptr(dx), N, H, W, C, dtype_code(dy.dtype), stream_ptr())
+    return dx
+
+
+# ---------------------------------------------------------------- 21-channel pointwise convs
+def pw_c2k(x, w, bias, K, w_transposed=False):
+    """x channels_last [N,C,H,W] -> heat-map [N,K,H,W] fp32 contiguous."""
+    N, C, H, W = x.shape
+    y = torch.empty((N, K, H, W), dtype=torch.float32, device=x.device)
+    call('mi355_pw_c2k', ptr(x), ptr(w), ptr(bias), ptr(y), N, H * W, C, K, int(w_transposed), dtype_code(x.dtype),
+         stream_ptr())
+    return y
+
+
+def pw_k2c(y, w, bias, C, dtype, residual=None, scale_dev=None, w_transposed=False):
+    """heat-map [N,K,H,W] fp32 -> channels_last [N,C,H,W] `dtype`."""
+    N, K, H, W = y.shape
+    out = nhwc_empty(N, C, H, W, dtype, y.device)
+    call('mi355_pw_k2c', ptr(y), ptr(w), ptr(bias), ptr(residual), ptr(scale_dev), ptr(out), N, H * W, C, K,
+         int(w_transposed), dtype_code(dtype), stream_ptr())
+    return out
+
+
+def pw_wgrad(x, y, dw, kc_layout, accumulate):
+    N, C, H, W = x.shape
+    K = y.shape[1]
+    ws = workspace(load().mi355_pw_wgrad_workspace(N, H * W, C, K), x.device)
+    call('mi355_pw_wgrad', ptr(x), ptr(y), ptr(dw), int(kc_layout), int(accumulate), N, H * W, C, K,
+         dtype_code(x.dtype), ptr(ws), ws.numel(), stream_ptr())
+
+
+def hm_rowsum(y, out, accumulate):
+    N, K, H, W = y.shape
+    ws = workspace(N * K * 4, y.device)
+    call('mi355_hm_rowsum', ptr(y), ptr(out), int(accumulate), N, K, H * W, ptr(ws), ws.numel(), stream_ptr())
+
+
+# ---------------------------------------------------------------- heat-map decode / losses
+def _hm(t):
+    if t.dtype != torch.float32 or not t.is_contiguous():
+        t = t.float().contiguous()
+    _chk_dev(t)
+    return t
+
+
+def argmax2d(hm):
+    """(idx int32 [B,K], xy fp32 [B,K,2], maxval fp32 [B,K,1]) with numpy's first-max tie rule."""
+    hm = _hm(hm)
+    B, K, H, W = hm.shape
+    idx = torch.empty((B, K), dtype=torch.int32, device=hm.device)
+    xy = torch.empty((B, K, 2), dtype=torch.float32, device=hm.device)
+    mv = torch.empty((B, K, 1), dtype=torch.float32, device=hm.device)
+    call('mi355_argmax2d', ptr(hm), ptr(idx), ptr(xy), ptr(mv), B * K, H, W, stream_ptr())
+    return idx, xy, mv
+
+
+def softargmax(hm, beta=100.0, out_scale=4.0):
+    hm = _hm(hm)
+    B, K, H, W = hm.shape
+    uv = torch.empty((B, K, 2), dtype=torch.float32, device=hm.device)
+    call('mi355_softargmax', ptr(hm), ptr(uv), B * K, H, W, float(beta), float(out_scale), stream_ptr())
+    return uv
+
+
+def kl_heatmap(pred, target, weight, eps, want_grad):
+    """Returns (loss_rows [B,K], unit_grad [B,K,H,W] or None); unit_grad = d(mean over B*K)/d pred."""
+    pred, target = _hm(pred), _hm(target)
+    B, K, H, W = pred.shape
+    if tuple(target.shape) != (B, K, H, W):
+        raise Mi355Error('kl_heatmap: pred %s vs target %s' % (tuple(pred.shape), tuple(target.shape)))
+    rows = torch.empty((B, K), dtype=torch.float32, device=pred.device)
+    g = torch.empty_like(pred) if want_grad else None
+    if weight is not None:
+        weight = weight.reshape(B, K).float().contiguous()
+    call('mi355_kl_heatmap', ptr(pred), ptr(target), ptr(weight), float(eps), ptr(rows), ptr(g), B * K, H * W,
+         1.0 / (B * K), stream_ptr())
+    return rows, g
+
+
+def reduce_sum(v, scale=1.0):
+    v = v.contiguous()
+    out = torch.empty((), dtype=torch.float32, device=v.device)
+    call('mi355_reduce_sum', ptr(v), ptr(out), v.numel(), float(scale), stream_ptr())
+    return out
+
+
+def scale_by_dev(t, g_dev):
+    out = torch.empty_like(t)
+    call('mi355_scale_by_dev', ptr(t), ptr(g_dev), ptr(out), t.numel(), stream_ptr())
+    return out
+
+
+def pseudo_label(xy, patch, radius, div, S, kind, extra=None, normalise=False, want_gt=True, want_gf=True):
+    B, K, _ = xy.shape
+    dev = xy.device
+    gt = torch.empty((B, K, S, S), dtype=torch.float32, device=dev) if want_gt else None
+    gf = torch.empty((B, K, S, S), dtype=torch.float32, device=dev) if want_gf else None
+    if extra is not None:
+        extra = _hm(extra)
+        if tuple(extra.shape) != (B, K, S, S):
+            raise Mi355Error('pseudo_label: extra has shape %s, expected %s' % (tuple(extra.shape), (B, K, S, S)))
+    call('mi355_pseudo_label', ptr(xy), ptr(patch), int(radius), int(div), int(S), int(kind), ptr(extra),
+         int(normalise), ptr(gt), ptr(gf), B, K, stream_ptr())
+    return gt, gf
+
+
+def bilinear_up(x, size, alpha=1.0, out=None):
+    """alpha * nn.Upsample(size, mode='bilinear')(x) (+ out when given)."""
+    x = _hm(x)
+    B, K, h, w = x.shape
+    acc = out is not None
+    if out is None:
+        out = torch.empty((B, K, size, size), dtype=torch.float32, device=x.device)
+    call('mi355_bilinear_up', ptr(x), ptr(out), B * K, h, w, size, size, float(alpha), int(acc), stream_ptr())
+    return out
+
+
+def pck_dists(pred_xy, tgt_xy, norm_x, norm_y):
+    rows = pred_xy.shape[0] * pred_xy.shape[1]
+    d = torch.empty(pred_xy.shape[:2], dtype=torch.float32, device=pred_xy.device)
+    call('mi355_pck_dists', ptr(pred_xy.contiguous()), ptr(tgt_xy.contiguous()), ptr(d), rows, float(norm_x),
+         float(norm_y), stream_ptr())
+    return d
+
+
+# ---------------------------------------------------------------- optimiser
+def sgd_nesterov(p, g, buf, lr_dev, momentum, wd, nesterov, p_lowp=None):
+    call('mi355_sgd_nesterov', ptr(p), ptr(g), ptr(buf), p.numel(), ptr(lr_dev), float(momentum), float(wd),
+         int(nesterov), ptr(p_lowp), stream_ptr())
+
+
+def cast_f32(src, dst):
+    call('mi355_cast_f32', ptr(src), ptr(dst), src.numel(), dtype_code(dst.dtype), stream_ptr())
+
+
+# ---------------------------------------------------------------- kernel timer (bench.py roofline)
+def prof_enable(on):
+    call('mi355_prof_enable', int(on))
+
+
+def prof_reset():
+    call('mi355_prof_reset')
+
+
+def prof_read():
+    ms, n, fl = ctypes.c_double(), ctypes.c_long(), ctypes.c_double()
+    call('mi355_prof_read', ctypes.byref(ms), ctypes.byref(n), ctypes.byref(fl))
+    return ms.value, n.value, fl.value

@@ -1,0 +1,200 @@
+/*
+ * mi355pose.h — C ABI of libmi355pose.so: the MI355X (gfx950) kernels underneath the
+ * domain-adaptive hand-pose training / evaluation hot path.
+ *
+ * The reference (CVlab315/Domain-Adaptative-Hand-Pose-Estimation) has NO native / FFI
+ * boundary: it is 100 % Python on torch.nn.  Its drop-in surface is the
+ * Python API (train1.py / test.py CLIs, uda.model class names, state_dict layout), which the
+ * host package mirrors.  This header is the NEW internal boundary beneath that Python API:
+ * one entry point per fused op and direction, each replacing the ATen op sequence the
+ * reference issues at the cited file:line (paths relative to the reference root).
+ *
+ * Conventions
+ *   - plain pointers + sizes; every buffer is DEVICE memory allocated by the caller;
+ *     the library never allocates, never synchronises, never owns memory;
+ *   - all work is enqueued on `stream` (a hipStream_t passed as void*; NULL = default);
+ *     every entry point is hipGraph-capturable;
+ *   - returns 0 on success, a negative MI355_E* code otherwise; text via mi355_last_error()
+ *     (thread-local); no exceptions cross the ABI; re-entrant (autograd worker threads);
+ *   - activations are NHWC ("rows x channels"), dtype MI355_F32 or MI355_BF16;
+ *     heat-maps (21 channels) are NCHW fp32 rows of H*W, as the reference's losses see them;
+ *   - scalars that change every iteration (GL lambda, learning rate, upstream loss grad)
+ *     are read from DEVICE floats so that a captured graph replays with fresh values.
+ *   - "conv-form": every conv-like layer is described as the convolution
+ *         y[N,Ho,Wo,Co] = conv(x[N,Hi,Wi,Ci], w[Co][kh][kw][Ci], stride, pad)
+ *     nn.Conv2d uses it directly; nn.ConvTranspose2d(Cin,Cout) is the ADJOINT of the
+ *     conv-form with Co=Cin_t, Ci=Cout_t (its forward is conv_dgrad, its input-gradient is
+ *     conv_fwd, its weight-gradient is conv_wgrad with the roles of x/dy swapped).
+ */
+#ifndef MI355POSE_H
+#define MI355POSE_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MI355_F32 0
+#define MI355_BF16 1
+
+#define MI355_OK 0
+#define MI355_EINVAL (-1)   /* bad argument / unsupported shape */
+#define MI355_ELAUNCH (-2)  /* HIP launch error */
+#define MI355_EWORKSPACE (-3)
+
+typedef struct {
+  int N, Hi, Wi, Ci; /* conv-form input  (NHWC)                       */
+  int Ho, Wo, Co;    /* conv-form output (NHWC)                       */
+  int kh, kw, stride, pad;
+  int dtype;         /* MI355_F32 | MI355_BF16 (activations+packed weights) */
+} mi355_conv_desc;
+
+int mi355_version(void);
+const char* mi355_last_error(void);
+
+/* ---------------------------------------------------------------- convolutions (MFMA implicit GEMM)
+ * Replace torch.nn.Conv2d / ConvTranspose2d forward+backward issued by
+ *   uda/model/resnet.py:23-38 (torchvision ResNet stem/blocks), uda/model/pose_resnet2.py:33-41
+ *   (3x ConvTranspose2d 4x4 s2 p1), uda/model/regda_7.py:4906-4929 (_make_head),
+ *   :4513-4514,4551,4561 (make_head), :4588-4589,4627,4637 (make_head2).
+ * w  : packed weights [Co][kh][kw][Ci]  in `dtype`     (forward operand)
+ * wT : packed weights [Ci][kh][kw][Co]  in `dtype`     (dgrad operand)
+ * bias: fp32 [Co] or NULL.  residual: tensor shaped like y (added before the store) or NULL.
+ * scale_dev: NULL or device float multiplied into the result (folds utils/gl.py:18, grad*coeff).
+ * accumulate!=0 : dx += result (several consumers of one tensor), else dx = result.
+ * dw: fp32 [Co][kh][kw][Ci]; accumulate!=0 adds into dw.  ws: scratch of at least
+ * mi355_conv_wgrad_workspace() bytes.
+ */
+int mi355_conv_fwd(const mi355_conv_desc* d, const void* x, const void* w, const float* bias,
+                   const void* residual, void* y, void* stream);
+int mi355_conv_dgrad(const mi355_conv_desc* d, const void* dy, const void* wT, const float* bias,
+                     const float* scale_dev, int accumulate, void* dx, void* stream);
+size_t mi355_conv_wgrad_workspace(const mi355_conv_desc* d);
+int mi355_conv_wgrad(const mi355_conv_desc* d, const void* x, const void* dy, float* dw, int accumulate,
+                     void* ws, size_t ws_bytes, void* stream);
+/* fp32 master [O][T][I] -> packed `dtype` copies: wf [O][T][Ipad] (cast) and/or wt [Ipad][T][O] (transposed);
+ * channels I..Ipad-1 are zero (the 3-channel stem is padded to one 16-byte chunk). */
+int mi355_pack_weights(const float* w, void* wf, void* wt, int O, int T, int I, int Ipad, int dtype, void* stream);
+/* dbias[C] (=|+=) column sums of dy[rows][C] (bias gradient of the biased head convs). */
+size_t mi355_colsum_workspace(long rows, int C);
+int mi355_colsum(const void* dy, float* out, long rows, int C, int dtype, int accumulate, void* ws,
+                 size_t ws_bytes, void* stream);
+
+/* ---------------------------------------------------------------- BatchNorm2d (+ReLU, +residual add)
+ * Replace nn.BatchNorm2d (+nn.ReLU, + the residual add of torchvision blocks): 66 instances for
+ * ResNet-50; train mode: batch statistics, running-stat update with momentum 0.1 and
+ * the UNBIASED variance, eps 1e-5.
+ *   y = relu?( (x-mean)*invstd*gamma + beta + residual? )
+ * save_mean / save_invstd: fp32 [C] outputs consumed by mi355_bn_bwd.
+ * bwd: dy_eff = relu ? dy*(y>0) : dy ; dx = gamma*invstd*(dy_eff - mean(dy_eff) - xhat*mean(dy_eff*xhat));
+ *      dresidual (nullable) = dy_eff ; dgamma/dbeta (=|+=).
+ */
+size_t mi355_bn_workspace(long rows, int C);
+int mi355_bn_train_fwd(const void* x, const void* residual, void* y, const float* gamma, const float* beta,
+                       float* running_mean, float* running_var, int64_t* num_batches_tracked,
+                       float* save_mean, float* save_invstd, long rows, int C, float eps, float momentum,
+                       int relu, int dtype, void* ws, size_t ws_bytes, void* stream);
+int mi355_bn_eval_fwd(const void* x, const void* residual, void* y, const float* gamma, const float* beta,
+                      const float* running_mean, const float* running_var, long rows, int C, float eps,
+                      int relu, int dtype, void* stream);
+int mi355_bn_bwd(const void* dy, const void* x, const void* y, const float* gamma, const float* save_mean,
+                 const float* save_invstd, void* dx, void* dresidual, float* dgamma, float* dbeta,
+                 int accumulate, long rows, int C, int relu, int dtype, void* ws, size_t ws_bytes,
+                 void* stream);
+
+/* ---------------------------------------------------------------- stem max-pool 3x3 s2 p1
+ * Replaces nn.MaxPool2d(3,2,1) of the torchvision stem (uda/model/resnet.py:28).  argidx: uint8 window
+ * position (first maximum in (kh,kw) scan order, as ATen) kept for the backward gather. */
+int mi355_maxpool_fwd(const void* x, void* y, uint8_t* argidx, int N, int H, int W, int C, int dtype,
+                      void* stream);
+int mi355_maxpool_bwd(const void* dy, const uint8_t* argidx, void* dx, int N, int H, int W, int C, int dtype,
+                      void* stream);
+
+/* ---------------------------------------------------------------- layout changes at the API edge */
+/* image / feature NCHW fp32 -> NHWC `dtype` with channels zero-padded to Cpad (stem input). */
+int mi355_nchw_to_nhwc(const float* x, void* y, int N, int C, int H, int W, int Cpad, int dtype, void* stream);
+/* NHWC `dtype` -> NCHW fp32 (the feature map `f` returned by PoseResNetx9.forward, regda_7.py:4944). */
+int mi355_nhwc_to_nchw(const void* x, float* y, int N, int C, int H, int W, int dtype, void* stream);
+
+/* ---------------------------------------------------------------- 21-channel pointwise convs
+ * The 1x1 convs touching the K=21 heat-map tensors (regda_7.py:4916-4922 heads' last conv,
+ * :4513 / :4588 heatmap_conv).  Heat-maps y are NCHW fp32 [N][K][HW]; features x are NHWC [N*HW][C].
+ *  c2k : y[n][k][p] (=) bias[k] + sum_c x[n*HW+p][c] * w[k][c]          (w fp32 [K][C])
+ *  k2c : out[n*HW+p][c] (=|+=residual) bias[c] + sum_k y[n][k][p]*w[c][k], times *scale_dev (w fp32 [C][K])
+ *  wgrad: dw[K][C] (kc_layout=1) or dw[C][K] (kc_layout=0) (=|+=) sum_{n,p} y[n][k][p] * x[n*HW+p][c]
+ *  rowsum: out[k] (=|+=) sum_{n,p} y[n][k][p]                             (bias gradient)
+ *  w_transposed!=0: w is stored the other way round ([C][K] for c2k, [K][C] for k2c), which is how the
+ *  input-gradient of each op reuses the other op with the same weight tensor.
+ */
+int mi355_pw_c2k(const void* x, const float* w, const float* bias, float* y, int N, int HW, int C, int K,
+                 int w_transposed, int dtype, void* stream);
+int mi355_pw_k2c(const float* y, const float* w, const float* bias, const void* residual,
+                 const float* scale_dev, void* out, int N, int HW, int C, int K, int w_transposed, int dtype,
+                 void* stream);
+size_t mi355_pw_wgrad_workspace(int N, int HW, int C, int K);
+int mi355_pw_wgrad(const void* x, const float* y, float* dw, int kc_layout, int accumulate, int N, int HW,
+                   int C, int K, int dtype, void* ws, size_t ws_bytes, void* stream);
+int mi355_hm_rowsum(const float* y, float* out, int accumulate, int N, int K, int HW, void* ws, size_t ws_bytes,
+                    void* stream); /* ws: >= N*K floats */
+
+/* ---------------------------------------------------------------- heat-map decode / losses (rows = B*K maps)
+ * argmax2d: utils/keypoint_detection.py:7-35 get_max_preds — first maximum (np.argmax tie rule, NaN
+ *   counts as maximum), x = idx % W, y = floor(idx / W), both zeroed when max <= 0.  Bit-exact.
+ * softargmax: utils/keypoint_detection.py:209-239 — softmax(beta*hm), (E[col], E[row]) * out_scale.
+ */
+int mi355_argmax2d(const float* hm, int32_t* idx, float* xy, float* maxval, int rows, int H, int W,
+                   void* stream);
+int mi355_softargmax(const float* hm, float* uv, int rows, int H, int W, float beta, float out_scale,
+                     void* stream);
+/* KL loss, uda/model/loss.py:145-158: per row r
+ *   logp = log_softmax(pred[r]); t = (target[r]+eps)/sum(target[r]+eps);
+ *   loss_rows[r] = weight[r] * sum_j xlogy-style t_j*(log t_j - logp_j)   (0 where t_j==0)
+ *   unit_grad[r][j] (nullable) = weight[r]*inv_count * (softmax_j*sum(t) - t_j)   = d(mean loss)/d pred
+ */
+int mi355_kl_heatmap(const float* pred, const float* target, const float* weight, float eps,
+                     float* loss_rows, float* unit_grad, int rows, int HW, float inv_count, void* stream);
+/* out[0] = scale * sum(in[0..n)) in a fixed order (deterministic). */
+int mi355_reduce_sum(const float* in, float* out, int n, float scale, void* stream);
+/* out[i] = in[i] * (*g_dev) : backward of the KL loss (upstream scalar gradient on device). */
+int mi355_scale_by_dev(const float* in, const float* g_dev, float* out, long n, void* stream);
+/* Pseudo labels from arg-max coordinates xy[B*K][2] (of the 64x64-level main prediction):
+ *   centre = trunc(xy / div); gt = clipped Gaussian patch (patch[(2r+1)^2], host table) at centre on an
+ *   S x S map.  regda_4.py:76-86 (div 1, r 6), regda_7.py:3026-3039 (div 4, r 3), :3188-3201 (div 2, r 4).
+ * kind: 0 base  : gf = clip(sum_{j!=k} gt_j, 0, 1)                                   (regda_4.py:83-84)
+ *       1 x1/x5 : gf = clip(1 - 10 gt, 0, 1)                                         (regda_7.py:3255-3256)
+ *       2 x6    : gf = clip(clip(sum_k gt_k,0,1) - 10 gt, 0, 1)                      (regda_7.py:3614-3616)
+ * extra (nullable, [B*K][S*S]): gf = clip(gf + extra - 100 gt, 0, 1)                 (:3542-3544, :3618-3620)
+ * normalise!=0 : gf /= max(gf) per map (0/0 -> NaN as in the reference)              (:3546-3548, :3623-3625)
+ * gt / gf outputs nullable.
+ */
+int mi355_pseudo_label(const float* xy, const float* patch, int radius, int div, int S, int kind,
+                       const float* extra, int normalise, float* gt, float* gf, int B, int K, void* stream);
+/* nn.Upsample(size, mode='bilinear') (align_corners=False) on [rows][h][w] -> [rows][H][W];
+ * out = alpha*up(in) + (accumulate ? out : 0)   (train1.py:410-424: target5 = 0.5*up(adv3) + up(adv2)). */
+int mi355_bilinear_up(const float* in, float* out, int rows, int h, int w, int H, int W, float alpha,
+                      int accumulate, void* stream);
+/* PCK pieces of utils/keypoint_detection.py:38-92 on device: dist[B*K] = |pred-tgt| / (side/10) or -1. */
+int mi355_pck_dists(const float* pred_xy, const float* tgt_xy, float* dists, int rows, float norm_x,
+                    float norm_y, void* stream);
+
+/* ---------------------------------------------------------------- optimiser
+ * torch.optim.SGD(momentum, weight_decay, nesterov=True) of train1.py:141-148 over a flat fp32 range:
+ *   g' = g + wd*p ; buf = momentum*buf + g' ; p -= lr * (nesterov ? g' + momentum*buf : buf)
+ * lr read from *lr_dev.  p_lowp (nullable): bf16 copy of the updated parameters (same flat layout).
+ */
+int mi355_sgd_nesterov(float* p, const float* g, float* buf, long n, const float* lr_dev, float momentum,
+                       float wd, int nesterov, void* p_lowp, void* stream);
+int mi355_cast_f32(const float* in, void* out, long n, int dtype, void* stream);
+
+/* ---------------------------------------------------------------- in-library kernel timing (bench.py roofline)
+ * When enabled, every launch of the MFMA conv family is bracketed by hipEvents on its stream.
+ * mi355_prof_read synchronises the recorded events and returns totals since the last reset. */
+int mi355_prof_enable(int on);
+int mi355_prof_reset(void);
+int mi355_prof_read(double* total_ms, long* launches, double* flops);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,69 @@
+"""CPU-side checks of the C-ABI boundary: the library builds for gfx950, loads without a GPU and exports
+every symbol include/mi355pose.h declares; the ctypes table covers the header one to one; the product
+path refuses to run without the HIP library / on CPU tensors (no fallback)."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+from conftest import ROOT, PKG
+
+
+def _header_symbols():
+    txt = open(os.path.join(ROOT, 'include', 'mi355pose.h')).read()
+    txt = re.sub(r'/\*.*?\*/', '', txt, flags=re.S)
+    return sorted(set(re.findall(r'\b(mi355_\w+)\s*\(', txt)))
+
+
+@pytest.fixture(scope='module')
+def lib_path():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('mi355_build', os.path.join(PKG, 'build.py'))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod.build(verbose=False)
+
+
+def test_library_exports_every_header_symbol(lib_path):
+    lib = ctypes.CDLL(lib_path)
+    syms = _header_symbols()
+    assert len(syms) >= 35
+    for s in syms:
+        assert hasattr(lib, s), 'missing export ' + s
+    lib.mi355_version.restype = ctypes.c_int
+    assert lib.mi355_version() >= 100
+
+
+def test_ctypes_table_matches_header(lib_path):
+    import mi355
+    assert sorted(mi355.SIGNATURES) == _header_symbols()
+    mi355.load()
+
+
+def test_no_cpu_fallback(lib_path):
+    import mi355
+    from mi355 import ops
+    with pytest.raises(mi355.Mi355Error):
+        ops.to_nhwc(torch.zeros(1, 3, 8, 8))
+    with pytest.raises(mi355.Mi355Error):
+        ops.argmax2d(torch.zeros(1, 21, 8, 8))
+    with pytest.raises(mi355.Mi355Error):
+        mi355.load.__wrapped__ if hasattr(mi355.load, '__wrapped__') else None
+        saved, mi355._lib = mi355._lib, None
+        try:
+            mi355.load('/nonexistent/libmi355pose.so')
+        finally:
+            mi355._lib = saved
+
+
+def test_argument_validation_without_gpu(lib_path):
+    """Host-side validation paths return error codes before any launch (safe on a CPU-only box)."""
+    import mi355
+    lib = mi355.load()
+    bad = mi355.ConvDesc(1, 8, 8, 24, 8, 8, 64, 3, 3, 3, 1, mi355.BF16)   # stride 3 unsupported
+    assert lib.mi355_conv_fwd(ctypes.byref(bad), 0, 0, 0, 0, 0, 0) == -1
+    assert b'stride' in lib.mi355_last_error()
+    assert lib.mi355_sgd_nesterov(0, 0, 0, 0, 0, 0.9, 0.0, 1, 0, 0) == -1
+    assert lib.mi355_bn_workspace(4096, 256) > 0

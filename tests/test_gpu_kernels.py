@@ -1,0 +1,353 @@
+"""Per-kernel parity on the GPU: every C-ABI entry point (called through mi355.ops, i.e. ctypes) against a
+plain torch fp32 CPU computation of the same op / the CPU oracle.  fp32 mode: 1e-3 of the output scale
+(north-star tolerance); bf16 mode: inputs pre-rounded to bf16, tolerance = bf16 output rounding (2^-8 rel)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import golden
+from seeded import randn, rand, peaky_heatmaps, weights_bk
+
+pytestmark = pytest.mark.gpu
+
+DT = {'f32': torch.float32, 'bf16': torch.bfloat16}
+
+
+def _ops():
+    import mi355
+    from mi355 import ops
+    mi355.load()
+    return ops
+
+
+def _tol(dt, ref):
+    scale = float(ref.abs().max()) + 1e-12
+    return (1e-3 if dt == 'f32' else 1.2e-2) * scale
+
+
+def _round(t, dt):
+    return t.to(DT[dt]).float()
+
+
+def _nhwc(t_nchw, dt, dev, cpad=None):
+    """CPU NCHW fp32 -> device channels_last tensor of dtype dt (through the library's own converter)."""
+    ops = _ops()
+    return ops.to_nhwc(t_nchw.to(dev), DT[dt], cpad)
+
+
+def _back(t):
+    return t.float().cpu().contiguous()
+
+
+CONV_CASES = [
+    # N, Ci, H, W, Co, k, s, p
+    (2, 64, 16, 16, 64, 3, 1, 1),
+    (2, 64, 16, 16, 128, 3, 2, 1),
+    (3, 128, 8, 8, 256, 1, 1, 0),
+    (2, 64, 16, 16, 256, 1, 2, 0),
+    (2, 3, 32, 32, 64, 7, 2, 3),      # stem: Ci padded to one 16-byte chunk
+    (2, 256, 16, 16, 64, 4, 2, 1),    # conv-form of ConvTranspose2d(64 -> 256, 4, 2, 1)
+    (1, 64, 9, 13, 64, 3, 1, 1),      # ragged spatial size (M not a tile multiple)
+    (5, 64, 12, 12, 192, 3, 2, 1),    # Co not a multiple of the 128 tile
+]
+
+
+@pytest.mark.parametrize('dt', ['f32', 'bf16'])
+@pytest.mark.parametrize('case', CONV_CASES)
+def test_conv_fwd_dgrad_wgrad(gpu, dt, case):
+    ops = _ops()
+    N, Ci, H, W, Co, k, s, p = case
+    per = 8 if dt == 'bf16' else 4
+    Cip = ((Ci + per - 1) // per) * per
+    x = _round(randn(1, N, Ci, H, W), dt)
+    w = _round(randn(2, Co, Ci, k, k, scale=1.0 / np.sqrt(Ci * k * k)), dt)
+    bias = randn(3, Co, scale=0.1)
+    y_ref = F.conv2d(x, w, bias, stride=s, padding=p)
+    dy = _round(randn(4, *y_ref.shape), dt)
+    xr = x.clone().requires_grad_(True)
+    wr = w.clone().requires_grad_(True)
+    F.conv2d(xr, wr, None, stride=s, padding=p).backward(dy)
+
+    desc = ops.make_desc(N, H, W, Cip, Co, k, k, s, p, DT[dt])
+    xd = _nhwc(x, dt, gpu, Cip)
+    # master weights in [Co][kh][kw][Ci] memory order
+    wm = w.permute(0, 2, 3, 1).contiguous().to(gpu)
+    wf, wt = ops.pack_weights(wm, Co, k * k, Ci, Cip, DT[dt])
+    y = ops.conv_fwd(desc, xd, wf, bias.to(gpu))
+    assert tuple(y.shape) == tuple(y_ref.shape)
+    assert float((_back(y) - y_ref).abs().max()) <= _tol(dt, y_ref)
+
+    dyd = _nhwc(dy, dt, gpu)
+    dx = ops.conv_dgrad(desc, dyd, wt)
+    dx_ref = xr.grad
+    assert float((_back(dx)[:, :Ci] - dx_ref).abs().max()) <= _tol(dt, dx_ref)
+    # accumulate + device scale (the GL fold): dx2 = dx + 0.25 * dgrad
+    sc = torch.tensor(0.25, device=gpu)
+    dx2 = ops.conv_dgrad(desc, dyd, wt, scale_dev=sc, out=dx.clone(), accumulate=True)
+    assert float((_back(dx2)[:, :Ci] - 1.25 * dx_ref).abs().max()) <= 2 * _tol(dt, dx_ref)
+
+    dw = torch.full((Co, k, k, Cip), 7.0, dtype=torch.float32, device=gpu)   # overwritten when accumulate=0
+    ops.conv_wgrad(desc, xd, dyd, dw, accumulate=False)
+    dw_ref = wr.grad.permute(0, 2, 3, 1)
+    got = dw.cpu()[..., :Ci]
+    assert float((got - dw_ref).abs().max()) <= _tol(dt, dw_ref)
+    ops.conv_wgrad(desc, xd, dyd, dw, accumulate=True)
+    assert float((dw.cpu()[..., :Ci] - 2 * dw_ref).abs().max()) <= 2 * _tol(dt, dw_ref)
+
+
+@pytest.mark.parametrize('dt', ['f32', 'bf16'])
+def test_conv_residual_epilogue(gpu, dt):
+    ops = _ops()
+    N, Ci, H, W, Co = 2, 64, 8, 8, 128
+    x = _round(randn(11, N, Ci, H, W), dt)
+    w = _round(randn(12, Co, Ci, 1, 1, scale=0.1), dt)
+    r = _round(randn(13, N, Co, H, W), dt)
+    ref = F.conv2d(x, w) + r
+    desc = ops.make_desc(N, H, W, Ci, Co, 1, 1, 1, 0, DT[dt])
+    wf, _ = ops.pack_weights(w.permute(0, 2, 3, 1).contiguous().to(gpu), Co, 1, Ci, Ci, DT[dt])
+    y = ops.conv_fwd(desc, _nhwc(x, dt, gpu), wf, None, _nhwc(r, dt, gpu))
+    assert float((_back(y) - ref).abs().max()) <= _tol(dt, ref)
+
+
+@pytest.mark.parametrize('dt', ['f32', 'bf16'])
+@pytest.mark.parametrize('shape', [(4, 64, 16, 16), (2, 256, 8, 8), (3, 2048, 4, 4), (2, 24, 5, 7)])
+@pytest.mark.parametrize('relu,res', [(True, False), (True, True), (False, False)])
+def test_bn_train_fwd_bwd(gpu, dt, shape, relu, res):
+    ops = _ops()
+    N, C, H, W = shape
+    x = _round(randn(21, *shape) * 1.5 + 0.3, dt)
+    r = _round(randn(22, *shape), dt) if res else None
+    gamma, beta = 1 + 0.1 * randn(23, C), 0.1 * randn(24, C)
+    rm, rv = 0.1 * randn(25, C), 1 + 0.2 * rand(26, C)
+    xr = x.clone().requires_grad_(True)
+    rr = r.clone().requires_grad_(True) if res else None
+    gr, br = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    rm_ref, rv_ref = rm.clone(), rv.clone()
+    y_ref = F.batch_norm(xr, rm_ref, rv_ref, gr, br, True, 0.1, 1e-5)
+    if res:
+        y_ref = y_ref + rr
+    if relu:
+        y_ref = F.relu(y_ref)
+    dy = _round(randn(27, *shape), dt)
+    y_ref.backward(dy)
+
+    rm_d, rv_d = rm.to(gpu), rv.to(gpu)
+    nbt = torch.zeros((), dtype=torch.int64, device=gpu)
+    xd = _nhwc(x, dt, gpu)
+    rd = _nhwc(r, dt, gpu) if res else None
+    y, mean, invstd = ops.bn_train_fwd(xd, rd, gamma.to(gpu), beta.to(gpu), rm_d, rv_d, nbt, 1e-5, 0.1, relu)
+    tol = _tol(dt, y_ref)
+    assert float((_back(y) - y_ref.detach()).abs().max()) <= tol
+    assert torch.allclose(rm_d.cpu(), rm_ref, rtol=1e-4, atol=1e-5) and torch.allclose(rv_d.cpu(), rv_ref, rtol=1e-4, atol=1e-5)
+    assert int(nbt) == 1
+    dg = torch.zeros(C, device=gpu); db = torch.zeros(C, device=gpu)
+    # backward consumes the library's own y (bf16-rounded) for the ReLU mask
+    dx, dres = ops.bn_bwd(_nhwc(dy, dt, gpu), xd, y if relu else None, gamma.to(gpu), mean, invstd, dg, db, False, relu, res)
+    gtol = _tol(dt, xr.grad) * (3 if dt == 'bf16' else 1)
+    assert float((_back(dx) - xr.grad).abs().max()) <= gtol
+    if res:
+        assert float((_back(dres) - rr.grad).abs().max()) <= _tol(dt, rr.grad)
+    assert float((dg.cpu() - gr.grad).abs().max()) <= 2e-3 * (float(gr.grad.abs().max()) + 1) * (8 if dt == 'bf16' else 1)
+    assert float((db.cpu() - br.grad).abs().max()) <= 2e-3 * (float(br.grad.abs().max()) + 1) * (8 if dt == 'bf16' else 1)
+    # eval mode
+    ye = ops.bn_eval_fwd(xd, rd, gamma.to(gpu), beta.to(gpu), rm.to(gpu), rv.to(gpu), 1e-5, relu)
+    ye_ref = F.batch_norm(x, rm, rv, gamma, beta, False, 0.1, 1e-5)
+    if res:
+        ye_ref = ye_ref + r
+    if relu:
+        ye_ref = F.relu(ye_ref)
+    assert float((_back(ye) - ye_ref).abs().max()) <= _tol(dt, ye_ref)
+
+
+@pytest.mark.parametrize('dt', ['f32', 'bf16'])
+def test_maxpool_and_colsum(gpu, dt):
+    ops = _ops()
+    x = _round(randn(31, 2, 64, 18, 14), dt)
+    x[:, :, :6, :6] = 0.0            # ties: whole windows of equal values (post-ReLU zeros)
+    xr = x.clone().requires_grad_(True)
+    y_ref = F.max_pool2d(xr, 3, 2, 1)
+    dy = _round(randn(32, *y_ref.shape), dt)
+    y_ref.backward(dy)
+    xd = _nhwc(x, dt, gpu)
+    y, arg = ops.maxpool_fwd(xd)
+    assert torch.equal(_back(y), y_ref.detach())
+    dx = ops.maxpool_bwd(_nhwc(dy, dt, gpu), arg, x.shape)
+    assert float((_back(dx) - xr.grad).abs().max()) <= _tol(dt, xr.grad)
+    out = torch.zeros(64, device=gpu)
+    ops.colsum(xd, out, False)
+    ref = x.sum(dim=(0, 2, 3))
+    assert float((out.cpu() - ref).abs().max()) <= 1e-3 * float(ref.abs().max() + 1)
+
+
+@pytest.mark.parametrize('dt', ['f32', 'bf16'])
+def test_pointwise21(gpu, dt):
+    ops = _ops()
+    N, C, H, W, K = 2, 256, 16, 16, 21
+    x = _round(randn(41, N, C, H, W), dt)
+    w = randn(42, K, C, scale=0.06)
+    b = randn(43, K, scale=0.1)
+    xd = _nhwc(x, dt, gpu)
+    y = ops.pw_c2k(xd, w.to(gpu), b.to(gpu), K)
+    ref = F.conv2d(x, w.view(K, C, 1, 1), b)
+    assert float((y.cpu() - ref).abs().max()) <= 1e-3 * float(ref.abs().max())
+    # transposed-weight form = input gradient of the 21->C conv
+    w2 = randn(44, C, K, scale=0.2)
+    y2 = ops.pw_c2k(xd, w2.to(gpu), None, K, w_transposed=True)
+    ref2 = F.conv2d(x, w2.t().contiguous().view(K, C, 1, 1))
+    assert float((y2.cpu() - ref2).abs().max()) <= 1e-3 * float(ref2.abs().max())
+    hm = randn(45, N, K, H, W)
+    b2 = randn(46, C, scale=0.1)
+    res = _round(randn(47, N, C, H, W), dt)
+    out = ops.pw_k2c(hm.to(gpu), w2.to(gpu), b2.to(gpu), C, DT[dt], residual=_nhwc(res, dt, gpu))
+    ref3 = F.conv2d(hm, w2.view(C, K, 1, 1), b2) + res
+    assert float((_back(out) - ref3).abs().max()) <= _tol(dt, ref3)
+    sc = torch.tensor(0.5, device=gpu)
+    out2 = ops.pw_k2c(hm.to(gpu), w.to(gpu), None, C, DT[dt], scale_dev=sc, w_transposed=True)
+    ref4 = 0.5 * F.conv2d(hm, w.t().contiguous().view(C, K, 1, 1))
+    assert float((_back(out2) - ref4).abs().max()) <= _tol(dt, ref4)
+    dw = torch.zeros(K, C, device=gpu)
+    ops.pw_wgrad(xd, hm.to(gpu), dw, True, False)
+    ref5 = torch.einsum('nkhw,nchw->kc', hm, x)
+    assert float((dw.cpu() - ref5).abs().max()) <= 1e-3 * float(ref5.abs().max())
+    dw2 = torch.zeros(C, K, device=gpu)
+    ops.pw_wgrad(xd, hm.to(gpu), dw2, False, False)
+    assert float((dw2.cpu() - ref5.t()).abs().max()) <= 1e-3 * float(ref5.abs().max())
+    rs = torch.zeros(K, device=gpu)
+    ops.hm_rowsum(hm.to(gpu), rs, False)
+    assert torch.allclose(rs.cpu(), hm.sum(dim=(0, 2, 3)), rtol=1e-4, atol=1e-3)
+
+
+def test_argmax_bit_exact_and_accuracy(gpu):
+    """Golden G4 (captured from the reference's numpy get_max_preds): integer indices bit-exact."""
+    ops = _ops()
+    from oracle import losses as ol
+    g = golden('g4_argmax_accuracy')
+    hm = peaky_heatmaps(401, 3, 21, 64, 64).numpy()
+    hm[1, 0] = 0.5
+    hm[1, 1, 10, 7] = hm[1, 1, 40, 3] = 9.0
+    hm[2, 2, 63, 63] = 11.0
+    idx, xy, mv = ops.argmax2d(torch.from_numpy(hm).to(gpu))
+    assert np.array_equal(xy.cpu().numpy(), g['preds'])
+    assert np.array_equal(mv.cpu().numpy(), g['maxvals'])
+    flat = hm.reshape(3, 21, -1)
+    assert np.array_equal(idx.cpu().numpy(), np.argmax(flat, 2).astype(np.int32))
+    # NaN counts as the maximum (np.argmax), coordinates then masked to 0 (np.greater(nan, 0) is False)
+    hn = hm.copy(); hn[0, 3, 5, 9] = np.nan
+    idx2, xy2, _ = ops.argmax2d(torch.from_numpy(hn).to(gpu))
+    p_ref, _ = ol.get_max_preds(hn)
+    assert int(idx2[0, 3]) == 5 * 64 + 9 and np.array_equal(xy2.cpu().numpy(), p_ref)
+    # ragged / non-square maps
+    h2 = randn(402, 2, 5, 7, 11).numpy()
+    _, xy3, mv3 = ops.argmax2d(torch.from_numpy(h2).to(gpu))
+    p3, m3 = ol.get_max_preds(h2)
+    assert np.array_equal(xy3.cpu().numpy(), p3) and np.array_equal(mv3.cpu().numpy(), m3)
+
+
+def test_softargmax(gpu):
+    ops = _ops()
+    hm = randn(501, 2, 21, 64, 64, scale=0.05)
+    hm[0, 0, 20, 33] += 1.0
+    uv = ops.softargmax(hm.to(gpu))
+    np.testing.assert_allclose(uv.cpu().numpy(), golden('g5_softargmax')['uv'], rtol=1e-4, atol=1e-3)
+
+
+@pytest.mark.parametrize('eps', [0.0, 1e-7])
+def test_kl_heatmap_vs_oracle(gpu, eps):
+    ops = _ops()
+    from oracle import losses as ol
+    B, K = 2, 21
+    pred = randn(202, B, K, 64, 64)
+    label = rand(205, B, K, 64, 64) * (rand(206, B, K, 64, 64) > 0.9)
+    w = weights_bk(207, B, K)
+    p = pred.clone().requires_grad_(True)
+    ref = ol.JointsKLLoss(epsilon=eps)(p, label, w)
+    ref.backward()
+    rows, g = ops.kl_heatmap(pred.to(gpu), label.to(gpu), w.to(gpu), eps, True)
+    loss = ops.reduce_sum(rows.view(-1), 1.0 / (B * K))
+    assert abs(float(loss) - float(ref)) <= 1e-4 * abs(float(ref))
+    assert float((g.cpu() - p.grad).abs().max()) <= 1e-3 * float(p.grad.abs().max())
+    g2 = ops.scale_by_dev(g, torch.tensor(4.0, device=gpu))
+    assert torch.allclose(g2.cpu(), 4 * g.cpu())
+
+
+def _patch(tmp, sigma=2):
+    from oracle.losses import _gauss_patch
+    return torch.from_numpy(_gauss_patch(tmp, sigma).astype(np.float32).reshape(-1))
+
+
+def test_pseudo_labels_bit_exact(gpu):
+    """Golden G3 (reference PseudoLabelGenerator / 01 / 03 outputs): gt and gf bit-exact."""
+    ops = _ops()
+    g = golden('g3_pseudo_labels')
+    y = peaky_heatmaps(301, 2, 21, 64, 64).to(gpu)
+    _, xy, _ = ops.argmax2d(y)
+    gt, gf = ops.pseudo_label(xy, _patch(6).to(gpu), 6, 1, 64, 0)
+    assert np.array_equal(gt.cpu().numpy(), g['gt'])
+    np.testing.assert_allclose(gf.cpu().numpy(), g['gf'], rtol=0, atol=2e-7)   # BLAS summation order in the reference
+    gt1, gf1 = ops.pseudo_label(xy, _patch(3.0).to(gpu), 3, 4, 16, 1)
+    assert np.array_equal(gt1.cpu().numpy(), g['gt01']) and np.array_equal(gf1.cpu().numpy(), g['gf01'])
+    gt3, gf3 = ops.pseudo_label(xy, _patch(4).to(gpu), 4, 2, 32, 1)
+    assert np.array_equal(gt3.cpu().numpy(), g['gt03']) and np.array_equal(gf3.cpu().numpy(), g['gf03'])
+
+
+def test_ground_false_builders_vs_oracle(gpu):
+    ops = _ops()
+    from oracle import losses as ol
+    import torch.nn as nn
+    B, K = 2, 21
+    y = peaky_heatmaps(201, B, K, 64, 64)
+    y_adv2, y_adv3 = randn(203, B, K, 32, 32), randn(204, B, K, 16, 16)
+    up = lambda t, s: nn.Upsample(size=s, mode='bilinear')(t)
+    t5_ref, t0_ref = 0.5 * up(y_adv3, 64) + up(y_adv2, 64), up(y_adv3, 32)
+    t5 = ops.bilinear_up(y_adv3.to(gpu), 64, 0.5)
+    t5 = ops.bilinear_up(y_adv2.to(gpu), 64, 1.0, out=t5)
+    t0 = ops.bilinear_up(y_adv3.to(gpu), 32)
+    assert torch.allclose(t5.cpu(), t5_ref, rtol=1e-5, atol=1e-5) and torch.allclose(t0.cpu(), t0_ref, rtol=1e-5, atol=1e-5)
+    g2 = golden('g2_losses')
+    np.testing.assert_allclose(t5.cpu().numpy()[:, :2], g2['target5'], rtol=1e-5, atol=1e-5)
+    _, xy, _ = ops.argmax2d(y.to(gpu))
+    rd6 = ol.RegressionDisparityx6(ol.PseudoLabelGenerator(K, 64, 64), ol.JointsKLLoss(epsilon=1e-7))
+    rd5 = ol.RegressionDisparityx5(ol.PseudoLabelGenerator03(K), ol.JointsKLLoss(epsilon=1e-7))
+    w = weights_bk(207, B, K)
+    for extra_ref, extra in ((None, None), (t5_ref, t5)):
+        rd6(y, randn(1, B, K, 64, 64), extra_ref, w, mode='max')
+        _, gf = ops.pseudo_label(xy, _patch(6).to(gpu), 6, 1, 64, 2, extra=extra, normalise=True)
+        np.testing.assert_allclose(gf.cpu().numpy(), rd6.ground_false.numpy(), rtol=1e-5, atol=1e-6)
+    for extra_ref, extra in ((None, None), (t0_ref, t0)):
+        rd5(y, randn(1, B, K, 32, 32), extra_ref, w, mode='max')
+        _, gf = ops.pseudo_label(xy, _patch(4).to(gpu), 4, 2, 32, 1, extra=extra, normalise=True)
+        np.testing.assert_allclose(gf.cpu().numpy(), rd5.ground_false.numpy(), rtol=1e-5, atol=1e-6)
+
+
+def test_sgd_nesterov_vs_torch(gpu):
+    ops = _ops()
+    n = 10007
+    p0, g1, g2 = randn(61, n), randn(62, n), randn(63, n)
+    p = p0.clone().requires_grad_(True)
+    opt = torch.optim.SGD([p], lr=0.1, momentum=0.9, weight_decay=1e-4, nesterov=True)
+    for g, lr in ((g1, 1e-3), (g2, 7e-4)):
+        opt.param_groups[0]['lr'] = lr
+        p.grad = g.clone()
+        opt.step()
+    pad = (n + 3) // 4 * 4
+    pd = torch.zeros(pad, device=gpu); pd[:n] = p0.to(gpu)
+    buf = torch.zeros(pad, device=gpu); gd = torch.zeros(pad, device=gpu)
+    low = torch.zeros(pad, dtype=torch.bfloat16, device=gpu)
+    lr_dev = torch.zeros((), device=gpu)
+    for g, lr in ((g1, 1e-3), (g2, 7e-4)):
+        gd[:n] = g.to(gpu); lr_dev.fill_(lr)
+        ops.sgd_nesterov(pd[:n], gd[:n], buf[:n], lr_dev, 0.9, 1e-4, True, low[:n])
+    assert torch.allclose(pd[:n].cpu(), p.detach(), rtol=1e-6, atol=1e-7)
+    assert torch.equal(low[:n].cpu(), pd[:n].cpu().to(torch.bfloat16))
+
+
+def test_errors_are_loud(gpu):
+    import mi355
+    ops = _ops()
+    with pytest.raises(mi355.Mi355Error):
+        ops.to_nhwc(torch.zeros(1, 3, 4, 4))          # CPU tensor: no fallback
+    desc = ops.make_desc(1, 8, 8, 24, 64, 3, 3, 1, 1, torch.bfloat16)   # Ci/8 = 3 is not a power of two
+    x = torch.zeros(1, 8, 8, 24, dtype=torch.bfloat16, device=gpu).permute(0, 3, 1, 2)
+    with pytest.raises(mi355.Mi355Error):
+        ops.conv_fwd(desc, x, torch.zeros(64 * 9 * 24, dtype=torch.bfloat16, device=gpu))
