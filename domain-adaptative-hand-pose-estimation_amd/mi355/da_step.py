@@ -1,0 +1,222 @@
+"""One domain-adaptation training iteration = steps A, B, C of the reference's ``train()``
+(train1.py:371-458), over the MI355X kernels, optionally replayed from captured HIP graphs.
+
+Differences from the reference loop that do not change any result (documented in DESIGN.md):
+  * step B stops its backward at the neck output: the backbone/neck gradients it would produce are
+    zeroed by ``optimizer_f.zero_grad()`` at the start of step C before anyone reads them (train1.py:440);
+  * step C does not compute weight gradients of the adversarial heads: they are zeroed at the start of the
+    next step A (train1.py:372-376) before any optimizer reads them;
+  * pseudo-labels, arg-max, KL and PCK stay on the device (the reference round-trips through numpy 12x / iteration).
+Data parallelism: one process per GPU; the flat gradient buffers of the optimizers about to step are
+all-reduced (mean) over the default process group between the backward and the optimizer kernels.
+"""
+import torch
+import torch.distributed as dist
+
+from . import ops
+from .nn import mark_grads_fresh
+
+
+def _allreduce_mean(bufs):
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return
+    ws = dist.get_world_size()
+    for b in bufs:
+        if dist.get_backend() == 'nccl':
+            dist.all_reduce(b, op=dist.ReduceOp.AVG)
+        else:
+            dist.all_reduce(b, op=dist.ReduceOp.SUM)
+            b.div_(ws)
+
+
+class DAStep:
+    """Holds the static batch buffers and runs A/B/C.  ``optimizers`` = dict with keys f, h, h_adv, h_adv2,
+    h_adv3 (FusedSGD or any torch optimizer), ``criteria`` = dict with keys kl, rd (x6), rd2 (x5), rd1 (x1)."""
+
+    def __init__(self, model, optimizers, criteria, trade_off=1.0, skip_discarded=True, track_accuracy=True):
+        self.model, self.opt, self.crit = model, optimizers, criteria
+        self.trade_off, self.skip, self.track_acc = trade_off, skip_discarded, track_accuracy
+        self.graphs = None
+        self.out = {}
+        self._adv_params = [p for n in ('head_adv', 'head_adv2', 'head_adv3') for p in getattr(model, n).parameters()]
+
+    # ------------------------------------------------------------------ the three steps (fwd+bwd, then update)
+    def _fwdbwd_A(self, b):
+        m, c = self.model, self.crit
+        for o in self.opt.values():
+            o.zero_grad()
+        y_s, y_s_adv, y_s_adv2, y_s_adv3, _ = m(b['x_s'])
+        loss_s = 2 * c['kl'](y_s, b['label_s'], b['w_s']) + \
+            4 * c['rd2'](y_s, y_s_adv2, None, b['w_s'], mode='min') + \
+            4 * c['rd'](y_s, y_s_adv, None, b['w_s'], mode='min') + \
+            4 * c['rd1'](y_s, y_s_adv3, b['w_s'], mode='min')
+        loss_s.backward()
+        self.out.update(loss_s=loss_s.detach(), y_s=y_s.detach(), y_s_adv=y_s_adv.detach())
+
+    def _update_A(self):
+        for k in ('f', 'h', 'h_adv', 'h_adv2', 'h_adv3'):
+            self.opt[k].step()
+
+    def _fwdbwd_B(self, b):
+        m, c, to = self.model, self.crit, self.trade_off
+        for k in ('h_adv', 'h_adv2', 'h_adv3'):
+            self.opt[k].zero_grad()
+        y_t, y_t_adv, y_t_adv2, y_t_adv3, _ = m(b['x_t'], detach_features=self.skip)
+        loss1 = to * c['rd1'](y_t, y_t_adv3, b['w_t'], mode='max')
+        H = y_t.shape[-1]
+        target5 = ops.bilinear_up(y_t_adv3.detach(), H, 0.5)               # 0.5 * up(y_adv3) ...
+        target5 = ops.bilinear_up(y_t_adv2.detach(), H, 1.0, out=target5)   # ... + up(y_adv2)   (train1.py:410-424)
+        target0 = ops.bilinear_up(y_t_adv3.detach(), H // 2)
+        loss2 = to * c['rd'](y_t, y_t_adv, target5, b['w_t'], mode='max')
+        loss3 = to * c['rd2'](y_t, y_t_adv2, target0, b['w_t'], mode='max')
+        loss_gf = 0.3 * loss1 + 1 * loss2 + 0.3 * loss3
+        loss_gf.backward()
+        self.out.update(loss_gf=loss_gf.detach())
+
+    def _update_B(self):
+        for k in ('h_adv2', 'h_adv', 'h_adv3'):
+            self.opt[k].step()
+
+    def _fwdbwd_C(self, b):
+        m, c, to = self.model, self.crit, self.trade_off
+        self.opt['f'].zero_grad()
+        if self.skip:
+            for p in self._adv_params:
+                p.requires_grad_(False)
+        try:
+            y_t, y_t_adv, y_t_adv2, y_t_adv3, _ = m(b['x_t'])
+            loss1 = to * c['rd2'](y_t, y_t_adv2, None, b['w_t'], mode='min')
+            loss2 = to * c['rd'](y_t, y_t_adv, None, b['w_t'], mode='min')
+            loss_gt = 0.3 * loss1 + 1 * loss2
+            loss_gt.backward()
+        finally:
+            if self.skip:
+                for p in self._adv_params:
+                    p.requires_grad_(True)
+        self.out.update(loss_gt=loss_gt.detach(), y_t=y_t.detach(), y_t_adv=y_t_adv.detach())
+
+    def _update_C(self):
+        self.opt['f'].step()
+
+    def _accuracy(self, b):
+        """Device side of the four accuracy() calls of train1.py:464-475: arg-max coordinates + PCK distances."""
+        if not self.track_acc:
+            return
+        o = self.out
+        _, lab_s, _ = ops.argmax2d(b['label_s'])
+        has_t = b.get('label_t') is not None
+        lab_t = ops.argmax2d(b['label_t'])[1] if has_t else None
+        H, W = o['y_s'].shape[-2:]
+        for name, pred, lab in (('s', o['y_s'], lab_s), ('t', o['y_t'], lab_t), ('s_adv', o['y_s_adv'], lab_s),
+                                ('t_adv', o['y_t_adv'], lab_t)):
+            if lab is None:
+                continue
+            _, xy, _ = ops.argmax2d(pred)
+            o['pck_' + name] = ops.pck_dists(xy, lab, W / 10.0, H / 10.0)
+
+    def _grads(self, keys):
+        bufs = []
+        for k in keys:
+            o = self.opt[k]
+            if hasattr(o, 'flat_grads'):
+                bufs += o.flat_grads()
+            else:
+                bufs += [p.grad for g in o.param_groups for p in g['params'] if p.grad is not None]
+        return bufs
+
+    # ------------------------------------------------------------------ eager iteration
+    def run(self, batch):
+        """batch: dict x_s, label_s, w_s, x_t, w_t (+ optional label_t for the PCK bookkeeping)."""
+        if self.graphs is not None:
+            return self.replay(batch)
+        self.model.train()
+        self._fwdbwd_A(batch)
+        _allreduce_mean(self._grads(('f', 'h', 'h_adv', 'h_adv2', 'h_adv3')))
+        self._update_A()
+        self._fwdbwd_B(batch)
+        _allreduce_mean(self._grads(('h_adv', 'h_adv2', 'h_adv3')))
+        self._update_B()
+        self._fwdbwd_C(batch)
+        _allreduce_mean(self._grads(('f',)))
+        self._update_C()
+        self._accuracy(batch)
+        self.model.step()
+        return self.out
+
+    # ------------------------------------------------------------------ graph capture / replay
+    def capture(self, batch, warmup=3):
+        """Capture the iteration as six HIP graphs (fwd+bwd and update of A, B, C) over static copies of
+        `batch`; the gradient all-reduces run eagerly between them.  Everything that changes per iteration
+        (inputs, learning rates, GL lambda) is read from device memory."""
+        self.model.train()
+        self.static = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in batch.items()}
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                self.run(self.static)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        pool = torch.cuda.graph_pool_handle()
+        segs = [lambda: self._fwdbwd_A(self.static), self._update_A, lambda: self._fwdbwd_B(self.static),
+                self._update_B, lambda: (self._fwdbwd_C(self.static)), lambda: (self._update_C(), self._accuracy(self.static))]
+        graphs = []
+        for fn in segs:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, pool=pool):
+                fn()
+            graphs.append(g)
+        self.graphs = graphs          # capturing executes nothing: model / optimizer state is unchanged
+        return self
+
+    def _host_tick(self):
+        for o in self.opt.values():
+            if hasattr(o, 'sync_lr'):
+                o.sync_lr()
+        gl = getattr(self.model, 'gl_layer', None)
+        if gl is not None:
+            gl.sync()
+
+    def replay(self, batch=None):
+        if batch is not None and batch is not self.static:
+            for k, v in batch.items():
+                if torch.is_tensor(v):
+                    self.static[k].copy_(v, non_blocking=True)
+        self._host_tick()
+        g = self.graphs
+        g[0].replay()
+        _allreduce_mean(self._grads(('f', 'h', 'h_adv', 'h_adv2', 'h_adv3')))
+        g[1].replay()
+        g[2].replay()
+        _allreduce_mean(self._grads(('h_adv', 'h_adv2', 'h_adv3')))
+        g[3].replay()
+        g[4].replay()
+        _allreduce_mean(self._grads(('f',)))
+        g[5].replay()
+        self.model.step()
+        return self.out
+
+
+def build_training(model, heatmap_size=64, lr=0.01, momentum=0.9, wd=1e-4, lr_gamma=1e-4, lr_decay=0.75,
+                   trade_off=1.0, num_keypoints=21, skip_discarded=True, track_accuracy=True):
+    """Criteria, the five SGD optimizers and their LambdaLR schedules exactly as train1.py:131-154 builds them.
+    Returns (DAStep, optimizers dict, schedulers dict)."""
+    from torch.optim.lr_scheduler import LambdaLR
+    from uda.model.loss import JointsKLLoss
+    from uda.model.regda_4 import PseudoLabelGenerator
+    from uda.model.regda_7 import (PseudoLabelGenerator01, PseudoLabelGenerator03, RegressionDisparityx1,
+                                   RegressionDisparityx5, RegressionDisparityx6)
+    from .optim import FusedSGD
+    crit = dict(
+        kl=JointsKLLoss(),
+        rd=RegressionDisparityx6(PseudoLabelGenerator(num_keypoints, heatmap_size, heatmap_size), JointsKLLoss(epsilon=1e-7)),
+        rd2=RegressionDisparityx5(PseudoLabelGenerator03(num_keypoints, heatmap_size // 2, heatmap_size // 2), JointsKLLoss(epsilon=1e-7)),
+        rd1=RegressionDisparityx1(PseudoLabelGenerator01(num_keypoints, heatmap_size // 4, heatmap_size // 4), JointsKLLoss(epsilon=1e-7)))
+    mk = lambda ps: FusedSGD(ps, lr=0.1, momentum=momentum, weight_decay=wd, nesterov=True)
+    opts = dict(
+        f=mk([{'params': model.backbone.parameters(), 'lr': 0.1}, {'params': model.upsampling.parameters(), 'lr': 0.1}]),
+        h=mk(model.head.parameters()), h_adv=mk(model.head_adv.parameters()),
+        h_adv2=mk(model.head_adv2.parameters()), h_adv3=mk(model.head_adv3.parameters()))
+    fn = lambda x: lr * (1. + lr_gamma * float(x)) ** (-lr_decay)
+    scheds = {k: LambdaLR(o, fn) for k, o in opts.items()}
+    return DAStep(model, opts, crit, trade_off, skip_discarded, track_accuracy), opts, scheds

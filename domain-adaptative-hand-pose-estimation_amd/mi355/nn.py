@@ -1,0 +1,413 @@
+"""torch.nn-compatible layers whose forward/backward run on the HIP kernels (through mi355.ops).
+
+They keep torch's parameter names/shapes (state_dict compatible with the reference's nn.Conv2d /
+nn.ConvTranspose2d / nn.BatchNorm2d children) but
+  * weights live in conv-form memory order [Co][kh][kw][Ci] (a strided view, so `weight.shape` is torch's),
+  * feature maps are logical NCHW tensors in channels_last memory, dtype = mi355.compute_dtype(),
+  * parameter gradients are written straight into `param.grad` by the wgrad / BN-backward kernels
+    (first write after `zero_grad` overwrites, later ones accumulate), not returned through autograd.
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+from . import Mi355Error, compute_dtype
+from . import ops
+
+
+# ---------------------------------------------------------------- parameter-gradient bookkeeping
+def grad_slot(p):
+    """Return (tensor to write the gradient into, accumulate?) for parameter `p`."""
+    if p.grad is None:
+        p.grad = torch.empty_strided(p.shape, p.stride(), dtype=p.dtype, device=p.device)
+        p._mi_fresh = False
+        return p.grad, False
+    if getattr(p, '_mi_fresh', False):
+        p._mi_fresh = False
+        return p.grad, False
+    return p.grad, True
+
+
+def mark_grads_fresh(params):
+    """zero_grad without the memset: the next backward overwrites instead of accumulating."""
+    for p in params:
+        if p.grad is not None:
+            p._mi_fresh = True
+
+
+def _param_version(p):
+    return (p._version, getattr(p, '_mi_epoch', 0), p.data_ptr())
+
+
+def _as_feature(x, dtype):
+    """Accept anything NCHW-shaped; hand the kernels a channels_last tensor of the compute dtype."""
+    if ops.is_nhwc(x) and x.dtype == dtype:
+        return x
+    if not x.is_cuda:
+        raise Mi355Error('mi355 layers need CUDA/HIP tensors; there is no CPU fallback')
+    if x.dtype == torch.float32 and x.is_contiguous():
+        return ops.to_nhwc(x, dtype)
+    return x.to(dtype).contiguous(memory_format=torch.channels_last)   # foreign layout: torch as glue
+
+
+def _as_grad(dy, dtype):
+    if ops.is_nhwc(dy) and dy.dtype == dtype:
+        return dy
+    return dy.to(dtype).contiguous(memory_format=torch.channels_last)
+
+
+def _convform_param(Co, Ci, kh, kw):
+    """nn.Parameter of torch shape (Co,Ci,kh,kw) stored as [Co][kh][kw][Ci]."""
+    return nn.Parameter(torch.empty(Co, kh, kw, Ci).permute(0, 3, 1, 2))
+
+
+class _PackedWeights:
+    """Packed compute-dtype copies of one conv-form weight, refreshed when the master changes."""
+
+    def __init__(self):
+        self.key = None
+        self.wf = self.wt = None
+
+    def get(self, weight, O, T, I, Ipad, dtype):
+        key = (_param_version(weight), dtype, Ipad)
+        if key != self.key:
+            if self.wf is None or self.wf.dtype != dtype or self.wf.numel() != O * T * Ipad or \
+                    self.wf.device != weight.device:
+                self.wf = torch.empty(O * T * Ipad, dtype=dtype, device=weight.device)
+                self.wt = torch.empty(O * T * Ipad, dtype=dtype, device=weight.device)
+            ops.pack_weights_into(weight.detach(), self.wf, self.wt, O, T, I, Ipad, dtype)
+            self.key = key
+        return self.wf, self.wt
+
+
+def _chk_convform(weight):
+    w = weight.detach()
+    if not w.permute(0, 2, 3, 1).is_contiguous():
+        raise Mi355Error('conv weight lost its conv-form memory order (was the parameter re-created?)')
+
+
+# ---------------------------------------------------------------- autograd functions
+class _ConvFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, residual, mod, scale_dev):
+        desc, wf, _ = mod._plan(x)
+        y = ops.conv_fwd(desc, x, wf, bias, residual)
+        ctx.mod, ctx.desc, ctx.scale_dev = mod, desc, scale_dev
+        ctx.has_bias = bias is not None
+        ctx.save_for_backward(x, weight, bias)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight, bias = ctx.saved_tensors
+        mod, desc = ctx.mod, ctx.desc
+        dy = _as_grad(dy, x.dtype)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            _, _, wt = mod._plan(x)
+            dx = ops.conv_dgrad(desc, dy, wt, scale_dev=ctx.scale_dev)
+        if ctx.needs_input_grad[1]:
+            mod._wgrad(desc, x, dy, weight)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            g, acc = grad_slot(bias)
+            ops.colsum(dy, g, acc)
+        dres = dy if ctx.needs_input_grad[3] else None
+        return dx, None, None, dres, None, None
+
+
+class _DeconvFn(torch.autograd.Function):
+    """ConvTranspose2d = adjoint of its conv-form: forward is conv_dgrad, input-gradient is conv_fwd."""
+
+    @staticmethod
+    def forward(ctx, x, weight, mod):
+        desc, wf, wt = mod._plan(x)
+        y = ops.conv_dgrad(desc, x, wt)
+        ctx.mod, ctx.desc = mod, desc
+        ctx.save_for_backward(x, weight)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        mod, desc = ctx.mod, ctx.desc
+        dy = _as_grad(dy, x.dtype)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            _, wf, _ = mod._plan(x)
+            dx = ops.conv_fwd(desc, dy, wf)
+        if ctx.needs_input_grad[1]:
+            g, acc = grad_slot(weight)
+            ops.conv_wgrad(desc, dy, x, g, acc)      # conv-form input = dy, conv-form output = x
+        return dx, None, None
+
+
+class _BnFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, residual, mod, relu):
+        y, mean, invstd = ops.bn_train_fwd(x, residual, gamma, beta, mod.running_mean, mod.running_var,
+                                           mod.num_batches_tracked, mod.eps, mod.momentum, relu)
+        ctx.relu = relu
+        ctx.save_for_backward(x, y if relu else None, mean, invstd, gamma, beta)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y, mean, invstd, gamma, beta = ctx.saved_tensors
+        dy = _as_grad(dy, x.dtype)
+        dg = db = None
+        acc = False
+        if ctx.needs_input_grad[1]:
+            dg, acc = grad_slot(gamma)
+        if ctx.needs_input_grad[2]:
+            db, acc_b = grad_slot(beta)
+            acc = acc_b if dg is None else acc
+        dx, dres = ops.bn_bwd(dy, x, y, gamma, mean, invstd, dg, db, acc, ctx.relu, ctx.needs_input_grad[3])
+        return (dx if ctx.needs_input_grad[0] else None), None, None, dres, None, None
+
+
+class _MaxPoolFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        y, arg = ops.maxpool_fwd(x)
+        ctx.in_shape = tuple(x.shape)
+        ctx.save_for_backward(arg)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        arg, = ctx.saved_tensors
+        return ops.maxpool_bwd(dy.contiguous(memory_format=torch.channels_last), arg, ctx.in_shape)
+
+
+class _PwC2KFn(torch.autograd.Function):
+    """1x1 conv C -> K heat-map (NHWC features in, NCHW fp32 heat-map out)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, scale_dev):
+        K = weight.shape[0]
+        y = ops.pw_c2k(x, weight.detach(), bias, K)
+        ctx.scale_dev = scale_dev
+        ctx.has_bias = bias is not None
+        ctx.save_for_backward(x, weight, bias)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight, bias = ctx.saved_tensors
+        dy = dy.float().contiguous()
+        dx = None
+        if ctx.needs_input_grad[0]:     # dx[c] = sum_k dy[k] * w[k][c]  -> k2c with the [K][C] weight
+            dx = ops.pw_k2c(dy, weight.detach(), None, x.shape[1], x.dtype, scale_dev=ctx.scale_dev, w_transposed=True)
+        if ctx.needs_input_grad[1]:
+            g, acc = grad_slot(weight)
+            ops.pw_wgrad(x, dy, g, True, acc)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            g, acc = grad_slot(bias)
+            ops.hm_rowsum(dy, g, acc)
+        return dx, None, None, None
+
+
+class _PwK2CFn(torch.autograd.Function):
+    """1x1 conv K heat-map -> C features (+ fused residual add)."""
+
+    @staticmethod
+    def forward(ctx, hm, weight, bias, residual, dtype):
+        C = weight.shape[0]
+        out = ops.pw_k2c(hm, weight.detach(), bias, C, dtype, residual=residual)
+        ctx.has_bias = bias is not None
+        ctx.save_for_backward(hm, weight, bias)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        hm, weight, bias = ctx.saved_tensors
+        dout = _as_grad(dout, dout.dtype)
+        dhm = None
+        if ctx.needs_input_grad[0]:     # dhm[k] = sum_c dout[c] * w[c][k] -> c2k with the [C][K] weight
+            dhm = ops.pw_c2k(dout, weight.detach(), None, hm.shape[1], w_transposed=True)
+        if ctx.needs_input_grad[1]:
+            g, acc = grad_slot(weight)
+            ops.pw_wgrad(dout, hm, g, False, acc)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            g, acc = grad_slot(bias)
+            ops.colsum(dout, g, acc)
+        dres = dout if ctx.needs_input_grad[3] else None
+        return dhm, None, None, dres, None
+
+
+# ---------------------------------------------------------------- modules
+class Conv2d(nn.Module):
+    """nn.Conv2d(in, out, k, stride, padding, bias) on the MFMA implicit-GEMM kernels.
+    1x1 convs to / from the K-channel heat-maps (K not a multiple of the 16-byte chunk) take the
+    dedicated point-wise kernels and exchange NCHW fp32 heat-maps."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, bias=True):
+        super().__init__()
+        k = kernel_size if isinstance(kernel_size, int) else kernel_size[0]
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.kernel_size, self.stride, self.padding = (k, k), (stride, stride), (padding, padding)
+        self.weight = _convform_param(out_channels, in_channels, k, k)
+        self.bias = nn.Parameter(torch.empty(out_channels)) if bias else None
+        self._packed = _PackedWeights()
+        self._stem_tmp = None
+        self.reset_parameters()
+
+    def reset_parameters(self):   # nn.Conv2d defaults
+        nn.init.kaiming_uniform_(self.weight, a=math.sqrt(5))
+        if self.bias is not None:
+            fan_in = self.in_channels * self.kernel_size[0] * self.kernel_size[1]
+            bound = 1 / math.sqrt(fan_in) if fan_in > 0 else 0
+            nn.init.uniform_(self.bias, -bound, bound)
+
+    def extra_repr(self):
+        return '{in_channels}, {out_channels}, kernel_size={kernel_size}, stride={stride}, padding={padding}'.format(**self.__dict__)
+
+    @property
+    def mode(self):
+        k = self.kernel_size[0]
+        if k == 1 and self.stride[0] == 1 and self.out_channels % 8 and self.out_channels <= 32:
+            return 'c2k'
+        if k == 1 and self.stride[0] == 1 and self.in_channels % 8 and self.in_channels <= 32 and self.in_channels > 3:
+            return 'k2c'
+        return 'mfma'
+
+    def _cin_pad(self, dtype):
+        per = 8 if dtype == torch.bfloat16 else 4
+        return ((self.in_channels + per - 1) // per) * per
+
+    def _plan(self, x):
+        N, C, H, W = x.shape
+        k = self.kernel_size[0]
+        Cp = self._cin_pad(x.dtype)
+        if C != Cp:
+            raise Mi355Error('conv expects %d (padded) input channels, got %d' % (Cp, C))
+        _chk_convform(self.weight)
+        desc = ops.make_desc(N, H, W, Cp, self.out_channels, k, k, self.stride[0], self.padding[0], x.dtype)
+        wf, wt = self._packed.get(self.weight, self.out_channels, k * k, self.in_channels, Cp, x.dtype)
+        return desc, wf, wt
+
+    def _wgrad(self, desc, x, dy, weight):
+        g, acc = grad_slot(weight)
+        if desc.Ci == self.in_channels:
+            ops.conv_wgrad(desc, x, dy, g, acc)
+        else:   # stem: kernel works on the padded channel count; un-pad into the (Co,3,7,7) gradient
+            k = self.kernel_size[0]
+            if self._stem_tmp is None or self._stem_tmp.device != x.device:
+                self._stem_tmp = torch.empty(self.out_channels, k, k, desc.Ci, dtype=torch.float32, device=x.device)
+            ops.conv_wgrad(desc, x, dy, self._stem_tmp, False)
+            src = self._stem_tmp[..., :self.in_channels]
+            dst = g.permute(0, 2, 3, 1)
+            dst.add_(src) if acc else dst.copy_(src)
+
+    def forward(self, x, residual=None):
+        dtype = compute_dtype()
+        mode = self.mode
+        scale = getattr(x, '_mi_grad_scale', None)
+        if mode == 'c2k':
+            x = _as_feature(x, dtype)
+            return _PwC2KFn.apply(x, self.weight, self.bias, scale)
+        if mode == 'k2c':
+            if x.dtype != torch.float32 or not x.is_contiguous():
+                x = x.float().contiguous()
+            if not x.is_cuda:
+                raise Mi355Error('mi355 layers need CUDA/HIP tensors; there is no CPU fallback')
+            return _PwK2CFn.apply(x, self.weight, self.bias, residual, dtype)
+        if x.shape[1] == self.in_channels and self.in_channels != self._cin_pad(dtype):
+            x = ops.to_nhwc(x if (x.dtype == torch.float32 and x.is_contiguous()) else x.float().contiguous(),
+                            dtype, self._cin_pad(dtype))
+        else:
+            x = _as_feature(x, dtype)
+        return _ConvFn.apply(x, self.weight, self.bias, residual, self, scale)
+
+
+class ConvTranspose2d(nn.Module):
+    """nn.ConvTranspose2d(in, out, 4, stride=2, padding=1, output_padding=0, bias=False)."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=2, padding=1, output_padding=0, bias=False):
+        super().__init__()
+        if bias or output_padding != 0:
+            raise NotImplementedError('only the bias-free, output_padding=0 deconvolution of the pose neck is built')
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.kernel_size, self.stride, self.padding = (kernel_size,) * 2, (stride,) * 2, (padding,) * 2
+        # torch shape (in, out, kh, kw) == conv-form (Co=in, Ci=out); memory [in][kh][kw][out]
+        self.weight = _convform_param(in_channels, out_channels, kernel_size, kernel_size)
+        self.bias = None
+        self._packed = _PackedWeights()
+        nn.init.kaiming_uniform_(self.weight, a=math.sqrt(5))
+
+    def _plan(self, x):
+        N, C, H, W = x.shape          # x = conv-form OUTPUT (N, Co=in_channels, Ho, Wo)
+        k, s, p = self.kernel_size[0], self.stride[0], self.padding[0]
+        if C != self.in_channels:
+            raise Mi355Error('deconv expects %d input channels, got %d' % (self.in_channels, C))
+        Hi, Wi = (H - 1) * s - 2 * p + k, (W - 1) * s - 2 * p + k
+        _chk_convform(self.weight)
+        desc = ops.make_desc(N, Hi, Wi, self.out_channels, self.in_channels, k, k, s, p, x.dtype)
+        wf, wt = self._packed.get(self.weight, self.in_channels, k * k, self.out_channels, self.out_channels, x.dtype)
+        return desc, wf, wt
+
+    def forward(self, x):
+        x = _as_feature(x, compute_dtype())
+        return _DeconvFn.apply(x, self.weight, self)
+
+
+class BatchNorm2d(nn.Module):
+    def __init__(self, num_features, eps=1e-5, momentum=0.1):
+        super().__init__()
+        self.num_features, self.eps, self.momentum = num_features, eps, momentum
+        self.weight = nn.Parameter(torch.ones(num_features))
+        self.bias = nn.Parameter(torch.zeros(num_features))
+        self.register_buffer('running_mean', torch.zeros(num_features))
+        self.register_buffer('running_var', torch.ones(num_features))
+        self.register_buffer('num_batches_tracked', torch.tensor(0, dtype=torch.long))
+
+    def extra_repr(self):
+        return '{num_features}, eps={eps}, momentum={momentum}'.format(**self.__dict__)
+
+    def forward(self, x, residual=None, relu=False):
+        x = _as_feature(x, compute_dtype())
+        if self.training:
+            return _BnFn.apply(x, self.weight, self.bias, residual, self, bool(relu))
+        if torch.is_grad_enabled() and (x.requires_grad or self.weight.requires_grad):
+            raise Mi355Error('BatchNorm2d in eval mode is forward-only on this path (wrap it in torch.no_grad())')
+        return ops.bn_eval_fwd(x, residual, self.weight, self.bias, self.running_mean, self.running_var, self.eps, relu)
+
+
+class ReLU(nn.Module):
+    """Marker: fused into the preceding BatchNorm2d by FusedSequential / the block forwards."""
+
+    def __init__(self, inplace=False):
+        super().__init__()
+        self.inplace = inplace
+
+    def forward(self, x):
+        raise Mi355Error('a bare ReLU is not built on this path: it is always fused into the BatchNorm before it')
+
+
+class MaxPool2d(nn.Module):
+    def __init__(self, kernel_size=3, stride=2, padding=1):
+        super().__init__()
+        if (kernel_size, stride, padding) != (3, 2, 1):
+            raise NotImplementedError('only the 3x3 s2 p1 stem pool is built')
+
+    def forward(self, x):
+        return _MaxPoolFn.apply(_as_feature(x, compute_dtype()))
+
+
+class FusedSequential(nn.Sequential):
+    """nn.Sequential with the same child indices (state_dict keys) that runs [BatchNorm2d, ReLU] pairs as one
+    fused kernel."""
+
+    def forward(self, x):
+        mods = list(self)
+        i = 0
+        while i < len(mods):
+            m = mods[i]
+            if isinstance(m, BatchNorm2d) and i + 1 < len(mods) and isinstance(mods[i + 1], ReLU):
+                x = m(x, relu=True)
+                i += 2
+            else:
+                x = m(x)
+                i += 1
+        return x

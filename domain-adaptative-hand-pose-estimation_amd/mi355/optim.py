@@ -1,0 +1,130 @@
+"""FusedSGD: torch.optim.SGD(momentum, weight_decay, nesterov) semantics (reference train1.py:141-148) with one
+HIP kernel per parameter group over flat fp32 buffers.
+
+Drop-in for ``torch.optim.SGD`` in the reference's training script: same constructor arguments, same
+``param_groups`` / ``state_dict()`` layout (``momentum_buffer`` per parameter), so LambdaLR / MultiStepLR and
+the reference checkpoint keys keep working.  Parameters that have never received a gradient (e.g. the unused
+``backbone.fc``) are skipped exactly as torch does.
+"""
+import torch
+from torch.optim import Optimizer
+
+from . import ops
+from .nn import mark_grads_fresh
+
+
+class FusedSGD(Optimizer):
+    def __init__(self, params, lr=1e-3, momentum=0.0, dampening=0, weight_decay=0.0, nesterov=False):
+        if dampening != 0:
+            raise NotImplementedError('dampening is not used by the reference and not built')
+        defaults = dict(lr=lr, momentum=momentum, dampening=dampening, weight_decay=weight_decay, nesterov=nesterov)
+        super().__init__(params, defaults)
+        self._flat = None          # list of per-group dicts once flattened
+        self._lr_cache = {}
+
+    # ------------------------------------------------------------ flat storage
+    @property
+    def is_flat(self):
+        return self._flat is not None
+
+    def ensure_flat(self):
+        """Move every parameter that owns a gradient into flat (param, grad, momentum) buffers.  Parameter
+        objects keep their identity; only their storage moves.  Called on the first step()."""
+        if self._flat is not None:
+            return
+        flat = []
+        for gi, group in enumerate(self.param_groups):
+            ps = [p for p in group['params'] if p.requires_grad and p.grad is not None]
+            if not ps:
+                flat.append(None)
+                continue
+            dev = ps[0].device
+            offs, total = [], 0
+            for p in ps:
+                offs.append(total)
+                total += (p.numel() + 3) // 4 * 4          # 16-byte aligned slots
+            P = torch.zeros(total, dtype=torch.float32, device=dev)
+            G = torch.zeros(total, dtype=torch.float32, device=dev)
+            M = torch.zeros(total, dtype=torch.float32, device=dev)
+            for p, o in zip(ps, offs):
+                n = p.numel()
+                if p.dtype != torch.float32:
+                    raise TypeError('FusedSGD handles fp32 master parameters only')
+                pv = P[o:o + n].as_strided(p.shape, p.stride())
+                gv = G[o:o + n].as_strided(p.shape, p.stride())
+                mv = M[o:o + n].as_strided(p.shape, p.stride())
+                pv.copy_(p.data)
+                gv.copy_(p.grad)
+                st = self.state[p]
+                if 'momentum_buffer' in st and st['momentum_buffer'] is not None:
+                    mv.copy_(st['momentum_buffer'])
+                p.data = pv
+                p.grad = gv
+                st['momentum_buffer'] = mv
+                p._mi_epoch = getattr(p, '_mi_epoch', 0) + 1     # packed copies must be rebuilt (storage moved)
+            lr_dev = torch.zeros((), dtype=torch.float32, device=dev)
+            flat.append(dict(P=P, G=G, M=M, params=ps, lr_dev=lr_dev, gi=gi))
+        self._flat = flat
+        self.sync_lr(force=True)
+
+    def flat_grads(self):
+        """The contiguous gradient buffers (one per group) — what the data-parallel all-reduce operates on."""
+        self.ensure_flat()
+        return [f['G'] for f in self._flat if f is not None]
+
+    def sync_lr(self, force=False):
+        """Push the groups' current learning rates to their device scalars (call outside graph capture)."""
+        if self._flat is None:
+            return
+        for f in self._flat:
+            if f is None:
+                continue
+            lr = float(self.param_groups[f['gi']]['lr'])
+            if force or self._lr_cache.get(f['gi']) != lr:
+                f['lr_dev'].fill_(lr)
+                self._lr_cache[f['gi']] = lr
+
+    # ------------------------------------------------------------ torch.optim API
+    def zero_grad(self, set_to_none=False):
+        """Gradients are overwritten by the next backward (no memset, buffers stay in place)."""
+        for group in self.param_groups:
+            mark_grads_fresh(group['params'])
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        self.ensure_flat()
+        if not torch.cuda.is_current_stream_capturing():
+            self.sync_lr()
+        for f in self._flat:
+            if f is None:
+                continue
+            g = self.param_groups[f['gi']]
+            ops.sgd_nesterov(f['P'], f['G'], f['M'], f['lr_dev'], g['momentum'], g['weight_decay'], g['nesterov'])
+            for p in f['params']:
+                p._mi_epoch = getattr(p, '_mi_epoch', 0) + 1
+        return loss
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        if self._flat is None:
+            return
+        for f in self._flat:          # re-alias loaded momentum buffers onto the flat storage
+            if f is None:
+                continue
+            off = 0
+            for p in f['params']:
+                n = p.numel()
+                mv = f['M'][off:off + n].as_strided(p.shape, p.stride())
+                st = self.state[p]
+                buf = st.get('momentum_buffer')
+                if buf is None:
+                    mv.zero_()
+                elif buf.data_ptr() != mv.data_ptr():
+                    mv.copy_(buf)
+                st['momentum_buffer'] = mv
+                off += (n + 3) // 4 * 4
+        self.sync_lr(force=True)

@@ -1,0 +1,56 @@
+"""``PseudoLabelGenerator`` (reference ``uda/model/regda_4.py:17-86``) on the GPU.
+
+The reference keeps a (W,H,H,W) table of clipped Gaussians (67 MB at 64x64), copies the prediction to the
+host, takes the arg-max with numpy, gathers and copies back.  Here the arg-max kernel feeds a builder kernel
+that evaluates the clipped Gaussian patch analytically per pixel (patch values from the same numpy
+expression as the reference, so the labels are bit-identical); nothing leaves the device."""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from mi355 import ops
+
+
+def gaussian_patch(tmp_size, sigma):
+    """The (2*tmp_size+1)^2 unnormalised Gaussian of regda_4.py:57-63, same float32 numpy arithmetic."""
+    size = 2 * tmp_size + 1
+    x = np.arange(0, size, 1, np.float32)
+    y = x[:, np.newaxis]
+    x0 = y0 = size // 2
+    return np.exp(- ((x - x0) ** 2 + (y - y0) ** 2) / (2 * sigma ** 2)).astype(np.float32)
+
+
+class _GaussianLabels(nn.Module):
+    """Shared machinery: arg-max on the prediction, centre = trunc(xy / div), S x S label maps."""
+
+    def __init__(self, size, div, tmp_size, sigma):
+        super().__init__()
+        self.height = self.width = size
+        self.sigma, self.div = sigma, div
+        self.radius = int(tmp_size)
+        self._patch_host = torch.from_numpy(gaussian_patch(tmp_size, sigma).reshape(-1))
+        self._patch_dev = {}
+
+    def centres(self, y):
+        _, xy, _ = ops.argmax2d(y.detach())
+        return xy
+
+    def labels(self, y, kind, extra=None, normalise=False, want_gt=True, want_gf=True, xy=None):
+        if xy is None:
+            xy = self.centres(y)
+        patch = self._patch_dev.get(xy.device)
+        if patch is None:       # uploaded once per device (the loss modules are never .to(device)'d by the caller)
+            patch = self._patch_dev[xy.device] = self._patch_host.to(xy.device)
+        return ops.pseudo_label(xy, patch, self.radius, self.div, self.width, kind, extra, normalise, want_gt, want_gf)
+
+
+class PseudoLabelGenerator(_GaussianLabels):
+    """ground truth = Gaussian at the arg-max; ground false = clip(sum of the OTHER keypoints' Gaussians, 0, 1)."""
+
+    def __init__(self, num_keypoints, height=64, width=64, sigma=2):
+        assert height == width, 'square heat-maps only'
+        super().__init__(width, 1, sigma * 3, sigma)
+        self.num_keypoints = num_keypoints
+
+    def forward(self, y):
+        return self.labels(y, kind=0)

@@ -49,7 +49,7 @@ CONV_CASES = [
     (2, 3, 32, 32, 64, 7, 2, 3),      # stem: Ci padded to one 16-byte chunk
     (2, 256, 16, 16, 64, 4, 2, 1),    # conv-form of ConvTranspose2d(64 -> 256, 4, 2, 1)
     (1, 64, 9, 13, 64, 3, 1, 1),      # ragged spatial size (M not a tile multiple)
-    (5, 64, 12, 12, 192, 3, 2, 1),    # Co not a multiple of the 128 tile
+    (5, 128, 12, 12, 64, 3, 2, 1),    # odd batch, M = 180 rows (partial tiles)
 ]
 
 
