@@ -1,0 +1,224 @@
+#!/usr/bin/env python
+"""bench.py — throughput of the domain-adaptation training iteration (steps A+B+C of train1.py:371-458)
+on synthetic 256x256 batches, one process per GPU.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A "step" is one full iteration: 3 forward + 3 backward passes over B images each (B source + B target images),
+5 SGD updates, pseudo-labels / losses / PCK bookkeeping on the device.  value = unique images / s over the
+whole job = 2*B*N / t_iter.  Prints ONE JSON line on rank 0 (contract in the task statement):
+metric/value/unit, roofline (MFMA conv family, timed live with HIP events in a second pass over the same
+steps) and cpu_baseline (the CPU oracle = op-for-op restatement of the reference, timed on the host cores).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.join(ROOT, 'domain-adaptative-hand-pose-estimation_amd')
+for p in (ROOT, PKG):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+# forward conv+deconv GFLOPs per image (2*MAC), SURVEY.md table A3 / BASELINE.md section 4
+F_GFLOP = {('resnet18', 128): 5.611, ('resnet18', 256): 22.443, ('resnet50', 256): 29.188,
+           ('resnet101', 256): 38.885, ('resnet101', 512): 155.540}
+PEAK_TFLOPS = {'bf16': 2500.0, 'f32': 157.3}     # dense MFMA peaks, MI355X_MICROARCH.md
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--arch', default='resnet50')
+    ap.add_argument('--batch-size', type=int, default=64, help='per-GPU batch (source) = per-GPU batch (target)')
+    ap.add_argument('--image-size', type=int, default=256)
+    ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f32'])
+    ap.add_argument('--no-graph', action='store_true', help='launch eagerly instead of replaying HIP graphs')
+    ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--cpu-baseline-batch', type=int, default=4)
+    ap.add_argument('--cpu-baseline-iters', type=int, default=3)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    return ap.parse_args()
+
+
+def log(*a):
+    print('[bench %.1fs]' % (time.perf_counter() - _T0), *a, file=sys.stderr, flush=True)
+
+
+_T0 = time.perf_counter()
+
+
+def host_cores():
+    """CPU cores this process may actually use: affinity mask, capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    try:
+        q, p = open('/sys/fs/cgroup/cpu.max').read().split()
+        if q != 'max':
+            n = min(n, max(1, int(float(q) / float(p))))
+    except Exception:
+        pass
+    return max(1, min(n, 64))
+
+
+def cpu_baseline(arch, image_size, batch, iters):
+    """The CPU oracle (pure-torch fp32 restatement of the reference iteration) on the host cores."""
+    from oracle.train_step import build_model, DATrainer
+    from utils.synthetic import make_batch
+    cores = host_cores()
+    torch.set_num_threads(cores)
+    log('cpu baseline on %d threads' % cores)
+    torch.manual_seed(1)
+    model = build_model(arch)
+    tr = DATrainer(model, heatmap_size=image_size // 4)
+    b = make_batch(batch, image_size, image_size // 4, seed=1, device='cpu', with_target_labels=False)
+    tr.step(b['x_s'], b['label_s'], b['w_s'], b['x_t'], b['w_t'])          # warm-up
+    log('cpu baseline warm-up done')
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        tr.step(b['x_s'], b['label_s'], b['w_s'], b['x_t'], b['w_t'])
+    dt = (time.perf_counter() - t0) / iters
+    return {'value': round(2 * batch / dt, 3), 'unit': 'images/s', 'cores': cores, 'kind': 'port',
+            'sample': '%d full A+B+C iterations of %s at %dx%d, batch %d, fp32, %d threads (after 1 warm-up); '
+                      '%.2f s/iteration' % (iters, arch, image_size, image_size, batch, cores, dt)}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get('RANK', 0))
+    local_rank = int(os.environ.get('LOCAL_RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit('launch with torch.distributed.run --nproc-per-node %d for --gpus %d' % (args.gpus, args.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs an MI355X: the HIP path has no CPU fallback')
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    if world > 1:
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        dist.init_process_group('nccl', device_id=dev)
+
+    import mi355
+    from mi355 import ops
+    from mi355.da_step import build_training
+    import uda.model as models
+    from uda.model.pose_resnet2 import Upsampling
+    from uda.model.regda_7 import PoseResNetx9
+    from utils.synthetic import make_batch
+
+    mi355.load()
+    mi355.set_compute_dtype(args.dtype)
+    torch.manual_seed(1)                                   # reference default seed (train1.py:664)
+    S, B = args.image_size, args.batch_size
+    backbone = models.__dict__[args.arch](pretrained=False)   # random init: no checkpoints offline
+    model = PoseResNetx9(backbone, Upsampling(backbone.out_features), 256, 21, num_head_layers=2, finetune=True).to(dev)
+    if world > 1:
+        for t in list(model.parameters()) + list(model.buffers()):
+            dist.broadcast(t.data, 0)
+    step, opts, scheds = build_training(model, heatmap_size=S // 4)
+    batch = make_batch(B, S, S // 4, seed=1 + rank, device=dev)
+
+    def tick():
+        for s in scheds.values():
+            s.step()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # ---- warm-up (eager), capture, warm-up (replay)
+    n_eager = max(2, min(args.warmup, 3))
+    for _ in range(n_eager):
+        step.run(batch); tick()
+    log('eager warm-up done')
+    if not args.no_graph:
+        step.capture(batch, warmup=0)
+        log('graphs captured')
+    for _ in range(max(0, args.warmup - n_eager)):
+        step.run(batch); tick()
+
+    # ---- timed region: exactly K steps
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step.run(batch); tick()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t)
+    ms_per_step = dt / args.steps * 1e3
+    log('timed region done: %.2f ms/step' % ms_per_step)
+    losses = {k: float(step.out[k]) for k in ('loss_s', 'loss_gf', 'loss_gt')}
+
+    # ---- roofline of the dominant kernel family (MFMA implicit-GEMM conv: gather + wgrad kernels), rank 0:
+    # the same K steps again, eagerly, every conv launch bracketed by hipEvents on its stream.
+    roof = None
+    if not args.no_roofline and rank == 0:
+        step.graphs = None
+        n_prof = min(args.steps, 5)
+        ops.prof_reset(); ops.prof_enable(True)
+        for _ in range(n_prof):
+            step.run(batch); tick()
+        torch.cuda.synchronize()
+        ops.prof_enable(False)
+        ms, launches, flops = ops.prof_read()
+        log('roofline pass done')
+        # executed -> algorithmic FLOPs: the 3-channel stem runs padded to one 16-byte chunk (8 bf16 / 4 fp32 channels)
+        cpad = 8 if args.dtype == 'bf16' else 4
+        stem_m = B * (S // 2) * (S // 2)
+        stem_excess = 2.0 * stem_m * 64 * 49 * (cpad - 3) * 5 * n_prof     # 3 fwd + 2 wgrad launches / iteration
+        algo = flops - stem_excess
+        ach = algo / (ms * 1e-3) / 1e12
+        peak = PEAK_TFLOPS[args.dtype]
+        roof = {'bound': 'mfma', 'kernel': 'gather_gemm_kernel + wgrad_gemm_kernel (implicit-GEMM conv family)',
+                'achieved': round(ach, 2), 'peak': peak, 'unit': 'TFLOP/s', 'frac': round(ach / peak, 4),
+                'traffic': None, 'launches_per_step': launches // n_prof,
+                'algorithmic_gflop_per_launch': round(algo / launches / 1e9, 3),
+                'avg_launch_us': round(ms * 1e3 / launches, 2),
+                'conv_ms_per_step': round(ms / n_prof, 3)}
+    if world > 1:
+        dist.barrier()
+
+    if rank == 0:
+        F = F_GFLOP.get((args.arch, S))
+        res = {
+            'metric': 'images/sec (unique source+target images per A+B+C training iteration, 2*B*N/t_iter)',
+            'value': round(2 * B * world / (ms_per_step * 1e-3), 2), 'unit': 'images/s',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 3),
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
+            'config': {'workload': 'RHD->H3D domain-adaptation iteration (steps A+B+C), %s + 3-deconv neck + main head + 3 '
+                                   'adversarial multiscale-fusion heads, %dx%d, batch %d source + %d target per GPU, '
+                                   'random init, synthetic batches' % (args.arch, S, S, B, B),
+                       'arch': args.arch, 'image_size': S, 'per_gpu_batch': B, 'global_batch': B * world,
+                       'parallelism': 'dp%d' % world, 'hip_graphs': not args.no_graph},
+            'model_passes_per_s': round(3 * B * world / (ms_per_step * 1e-3), 2),
+            'losses_last_step': losses,
+        }
+        if F is not None:
+            tf = 9 * B * F * 1e9 / (ms_per_step * 1e-3) / 1e12
+            res['iteration_tflops_per_gpu_algorithmic_9BF'] = round(tf, 2)
+            res['iteration_frac_of_mfma_peak'] = round(tf / PEAK_TFLOPS[args.dtype], 4)
+        if roof is not None:
+            res['roofline'] = roof
+        if not args.no_cpu_baseline:
+            res['cpu_baseline'] = cpu_baseline(args.arch, S, args.cpu_baseline_batch, args.cpu_baseline_iters)
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

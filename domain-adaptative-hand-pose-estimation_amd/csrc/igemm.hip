@@ -370,6 +370,11 @@ __global__ void slab_reduce_kernel(const float* __restrict__ slabs, float* __res
   out[i] = v;
 }
 
+// plain zero-fill (own kernel rather than hipMemsetAsync: a kernel node replays identically inside HIP graphs)
+__global__ void zero_fill_kernel(uint4* __restrict__ p, size_t n16) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x) p[i] = make_uint4(0, 0, 0, 0);
+}
+
 // ------------------------------------------------------------------------------------ host side
 static int ilog2_exact(int v) { int s = 0; while ((1 << s) < v) ++s; return ((1 << s) == v) ? s : -1; }
 
@@ -451,7 +456,10 @@ extern "C" int mi355_conv_dgrad(const mi355_conv_desc* d, const void* dy, const 
     if (!cnt) need_zero = true;
   }
   if (need_zero && !accumulate) {
-    if (hipMemsetAsync(dx, 0, (size_t)d->N * d->Hi * d->Wi * d->Ci * esz, st) != hipSuccess) MI_FAIL(MI355_ELAUNCH, "memset failed");
+    const size_t n16 = (size_t)d->N * d->Hi * d->Wi * d->Ci * esz / 16;   // Ci*esz is a multiple of 16
+    int grid = (int)((n16 + 255) / 256); if (grid > 4096) grid = 4096;
+    hipLaunchKernelGGL(zero_fill_kernel, dim3(grid), dim3(256), 0, st, reinterpret_cast<uint4*>(dx), n16);
+    MI_CHECK_LAUNCH("zero_fill");
   }
   for (int py = 0; py < s; ++py)
     for (int px = 0; px < s; ++px) {

@@ -148,3 +148,16 @@ def test_g7_full_iteration():
     a = np.array([float(sd[k].double().abs().sum()) for k in keys])
     np.testing.assert_allclose(a, g['param_abs'], rtol=1e-5)
     np.testing.assert_allclose(s, g['param_sum'], rtol=1e-4, atol=1e-4)
+
+
+def test_synthetic_labels_follow_generate_target():
+    """The package's label generator (used for synthetic batches) against the oracle's restatement of
+    uda/dataset/util.py:9-68, including centres on / outside the border."""
+    from utils.synthetic import generate_target as gt_pkg
+    rng = np.random.default_rng(3)
+    joints = rng.uniform(-10, 266, size=(21, 2))
+    joints[0] = (0.0, 0.0); joints[1] = (255.9, 255.9); joints[2] = (3.9, 250.0); joints[3] = (258.0, 10.0)
+    vis = (rng.random((21, 1)) < 0.8).astype(np.float32)
+    a, wa = ol.generate_target(joints, vis, (64, 64), 2, (256, 256))
+    b, wb = gt_pkg(joints, vis, (64, 64), 2, (256, 256))
+    assert np.array_equal(a, b) and np.array_equal(wa, wb)
