@@ -14,7 +14,7 @@ static BnPlan bn_plan(long rows, int C, int CH) {
   p.TY = 256 / p.TX;
   p.colgroups = cdiv(p.cpr, p.TX);
   long want = rows / ((long)p.TY * 8); if (want < 1) want = 1;
-  long cap = 1536 / p.colgroups; if (cap < 1) cap = 1;
+  long cap = 1024 / p.colgroups; if (cap < 1) cap = 1;
   if (want > cap) want = cap;
   long rps = (rows + want - 1) / want; rps = ((rps + p.TY - 1) / p.TY) * p.TY;
   p.rows_per_slice = (int)rps; p.nslices = (int)((rows + rps - 1) / rps);
@@ -78,19 +78,30 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const T* __restrict__ x, 
   }
 }
 
-// one thread per channel: combine slices, update running stats, emit scale/shift
-__global__ void bn_finalize_kernel(const float* __restrict__ partial, int nslices, int C, const float* __restrict__ gamma,
+// 256-thread block = 8 channels x 32 slice-lanes: each lane folds its slices (s = lane, lane+32, ...) with Chan's
+// update, lanes are folded in lane order through LDS (fixed order -> bitwise reproducible), then lane 0 updates the
+// running statistics and emits scale/shift.
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ partial, int nslices, int C, const float* __restrict__ gamma,
                                    const float* __restrict__ beta, float* running_mean, float* running_var,
                                    int64_t* nbt, float* save_mean, float* save_invstd, float* scale_shift, float eps,
                                    float momentum) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c == 0 && nbt) *nbt += 1;
-  if (c >= C) return;
+  __shared__ float sn[256], sm[256], sv[256];
+  const int cl = threadIdx.x & 7, lane = threadIdx.x >> 3;
+  const int c = blockIdx.x * 8 + cl;
+  if (blockIdx.x == 0 && threadIdx.x == 0 && nbt) *nbt += 1;
   float n = 0.f, mean = 0.f, m2 = 0.f;
-  for (int s = 0; s < nslices; ++s) {
-    const float* q = partial + ((size_t)s * C + c) * 3;
-    const float nb = q[0];
-    if (nb > 0.f) { const float nt = n + nb, f = nb / nt, d = q[1] - mean; mean += d * f; m2 += q[2] + d * d * n * f; n = nt; }
+  if (c < C)
+    for (int s = lane; s < nslices; s += 32) {
+      const float* q = partial + ((size_t)s * C + c) * 3;
+      const float nb = q[0];
+      if (nb > 0.f) { const float nt = n + nb, f = nb / nt, d = q[1] - mean; mean += d * f; m2 += q[2] + d * d * n * f; n = nt; }
+    }
+  sn[threadIdx.x] = n; sm[threadIdx.x] = mean; sv[threadIdx.x] = m2;
+  __syncthreads();
+  if (lane != 0 || c >= C) return;
+  for (int l = 1; l < 32; ++l) {
+    const int o = l * 8 + cl; const float nb = sn[o];
+    if (nb > 0.f) { const float nt = n + nb, f = nb / nt, d = sm[o] - mean; mean += d * f; m2 += sv[o] + d * d * n * f; n = nt; }
   }
   const float var = m2 / n;
   const float invstd = 1.0f / sqrtf(var + eps);
@@ -185,13 +196,20 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
 }
 
 // coeff[c] = (k0 = gamma*invstd, k1 = mean(dy_eff), k2 = mean(dy_eff*xhat)); dgamma/dbeta (=|+=)
-__global__ void bn_bwd_finalize_kernel(const float* __restrict__ partial, int nslices, int C, float inv_rows,
+// block = 8 channels x 32 slice-lanes, folded in a fixed order (see bn_finalize_kernel)
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ partial, int nslices, int C, float inv_rows,
                                        const float* __restrict__ gamma, const float* __restrict__ invstd, float* dgamma,
                                        float* dbeta, int accumulate, float* coeff) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+  __shared__ float a1[256], a2[256];
+  const int cl = threadIdx.x & 7, lane = threadIdx.x >> 3;
+  const int c = blockIdx.x * 8 + cl;
   float s1 = 0.f, s2 = 0.f;
-  for (int s = 0; s < nslices; ++s) { const float* q = partial + ((size_t)s * C + c) * 2; s1 += q[0]; s2 += q[1]; }
+  if (c < C)
+    for (int s = lane; s < nslices; s += 32) { const float* q = partial + ((size_t)s * C + c) * 2; s1 += q[0]; s2 += q[1]; }
+  a1[threadIdx.x] = s1; a2[threadIdx.x] = s2;
+  __syncthreads();
+  if (lane != 0 || c >= C) return;
+  for (int l = 1; l < 32; ++l) { s1 += a1[l * 8 + cl]; s2 += a2[l * 8 + cl]; }
   if (dbeta) dbeta[c] = (accumulate ? dbeta[c] : 0.f) + s1;
   if (dgamma) dgamma[c] = (accumulate ? dgamma[c] : 0.f) + s2;
   if (coeff) { coeff[c] = gamma[c] * invstd[c]; coeff[C + c] = s1 * inv_rows; coeff[2 * C + c] = s2 * inv_rows; }
@@ -226,11 +244,17 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
   }
 }
 
-__global__ void colsum_finalize_kernel(const float* __restrict__ partial, int nslices, int C, float* out, int accumulate) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+__global__ __launch_bounds__(256) void colsum_finalize_kernel(const float* __restrict__ partial, int nslices, int C, float* out, int accumulate) {
+  __shared__ float a1[256];
+  const int cl = threadIdx.x & 7, lane = threadIdx.x >> 3;
+  const int c = blockIdx.x * 8 + cl;
   float s = 0.f;
-  for (int i = 0; i < nslices; ++i) s += partial[((size_t)i * C + c) * 2];
+  if (c < C)
+    for (int i = lane; i < nslices; i += 32) s += partial[((size_t)i * C + c) * 2];
+  a1[threadIdx.x] = s;
+  __syncthreads();
+  if (lane != 0 || c >= C) return;
+  for (int l = 1; l < 32; ++l) s += a1[l * 8 + cl];
   out[c] = (accumulate ? out[c] : 0.f) + s;
 }
 
@@ -261,7 +285,7 @@ extern "C" int mi355_bn_train_fwd(const void* x, const void* residual, void* y, 
   dim3 g(p.colgroups, p.nslices);
   if (dtype == MI355_BF16) hipLaunchKernelGGL(bn_stats_kernel<bf16_t>, g, dim3(256), 0, st, (const bf16_t*)x, partial, rows, C, p.TX, p.rows_per_slice);
   else hipLaunchKernelGGL(bn_stats_kernel<float>, g, dim3(256), 0, st, (const float*)x, partial, rows, C, p.TX, p.rows_per_slice);
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 256)), dim3(256), 0, st, partial, p.nslices, C, gamma, beta, running_mean, running_var, nbt, save_mean, save_invstd, ss, eps, momentum);
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 8)), dim3(256), 0, st, partial, p.nslices, C, gamma, beta, running_mean, running_var, nbt, save_mean, save_invstd, ss, eps, momentum);
   dim3 ga = apply_grid(p, rows);
   const float* nf = nullptr;
   if (dtype == MI355_BF16) hipLaunchKernelGGL((bn_apply_kernel<bf16_t, false>), ga, dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)residual, (bf16_t*)y, (const float*)ss, nf, nf, nf, nf, eps, rows, C, p.TX, relu);
@@ -297,7 +321,7 @@ extern "C" int mi355_bn_bwd(const void* dy, const void* x, const void* y, const 
   dim3 g(p.colgroups, p.nslices);
   if (dtype == MI355_BF16) hipLaunchKernelGGL((bn_bwd_reduce_kernel<bf16_t, true>), g, dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)x, (const bf16_t*)y, save_mean, save_invstd, partial, rows, C, p.TX, p.rows_per_slice, relu);
   else hipLaunchKernelGGL((bn_bwd_reduce_kernel<float, true>), g, dim3(256), 0, st, (const float*)dy, (const float*)x, (const float*)y, save_mean, save_invstd, partial, rows, C, p.TX, p.rows_per_slice, relu);
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 256)), dim3(256), 0, st, partial, p.nslices, C, 1.0f / (float)rows, gamma, save_invstd, dgamma, dbeta, accumulate, coeff);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 8)), dim3(256), 0, st, partial, p.nslices, C, 1.0f / (float)rows, gamma, save_invstd, dgamma, dbeta, accumulate, coeff);
   dim3 ga = apply_grid(p, rows);
   if (dtype == MI355_BF16) hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, ga, dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)x, (const bf16_t*)y, save_mean, save_invstd, coeff, (bf16_t*)dx, (bf16_t*)dresidual, rows, C, p.TX, relu);
   else hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, ga, dim3(256), 0, st, (const float*)dy, (const float*)x, (const float*)y, save_mean, save_invstd, coeff, (float*)dx, (float*)dresidual, rows, C, p.TX, relu);
@@ -315,7 +339,7 @@ extern "C" int mi355_colsum(const void* dy, float* out, long rows, int C, int dt
   dim3 g(p.colgroups, p.nslices);
   if (dtype == MI355_BF16) hipLaunchKernelGGL((bn_bwd_reduce_kernel<bf16_t, false>), g, dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)nullptr, (const bf16_t*)nullptr, (const float*)nullptr, (const float*)nullptr, partial, rows, C, p.TX, p.rows_per_slice, 0);
   else hipLaunchKernelGGL((bn_bwd_reduce_kernel<float, false>), g, dim3(256), 0, st, (const float*)dy, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, partial, rows, C, p.TX, p.rows_per_slice, 0);
-  hipLaunchKernelGGL(colsum_finalize_kernel, dim3(cdiv(C, 256)), dim3(256), 0, st, partial, p.nslices, C, out, accumulate);
+  hipLaunchKernelGGL(colsum_finalize_kernel, dim3(cdiv(C, 8)), dim3(256), 0, st, partial, p.nslices, C, out, accumulate);
   MI_CHECK_LAUNCH("colsum");
   return MI355_OK;
 }

@@ -151,12 +151,19 @@ __global__ __launch_bounds__(256) void pw_wgrad_kernel(const T* __restrict__ x, 
   }
 }
 
-__global__ void pw_wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw, int nslices, int K, int C, int kc_layout, int accumulate) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= K * C) return;
-  const int k = i / C, c = i % C;
+// block = 32 outputs x 8 slice-lanes; lanes folded in a fixed order
+__global__ __launch_bounds__(256) void pw_wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw, int nslices, int K, int C, int kc_layout, int accumulate) {
+  __shared__ float a1[256];
+  const int il = threadIdx.x & 31, lane = threadIdx.x >> 5;
+  const int i = blockIdx.x * 32 + il;
   float s = 0.f;
-  for (int sidx = 0; sidx < nslices; ++sidx) s += partial[(size_t)sidx * K * C + i];
+  if (i < K * C)
+    for (int sidx = lane; sidx < nslices; sidx += 8) s += partial[(size_t)sidx * K * C + i];
+  a1[threadIdx.x] = s;
+  __syncthreads();
+  if (lane != 0 || i >= K * C) return;
+  for (int l = 1; l < 8; ++l) s += a1[l * 32 + il];
+  const int k = i / C, c = i % C;
   const int o = kc_layout ? i : c * K + k;
   dw[o] = (accumulate ? dw[o] : 0.f) + s;
 }
@@ -215,7 +222,7 @@ extern "C" int mi355_pw_k2c(const float* y, const float* w, const float* bias, c
 
 static int pw_slices(int N, int HW, int* pps) {
   long P = (long)N * HW;
-  long per = ((P + 1023) / 1024 + 63) / 64 * 64; if (per < 64) per = 64;
+  long per = ((P + 511) / 512 + 63) / 64 * 64; if (per < 64) per = 64;
   *pps = (int)per;
   return (int)((P + per - 1) / per);
 }
@@ -233,7 +240,7 @@ extern "C" int mi355_pw_wgrad(const void* x, const float* y, float* dw, int kc_l
   float* partial = reinterpret_cast<float*>(ws);
   if (dtype == MI355_BF16) hipLaunchKernelGGL(pw_wgrad_kernel<bf16_t>, grid, dim3(256), 0, as_stream(stream), (const bf16_t*)x, y, partial, N, HW, C, K, pps);
   else hipLaunchKernelGGL(pw_wgrad_kernel<float>, grid, dim3(256), 0, as_stream(stream), (const float*)x, y, partial, N, HW, C, K, pps);
-  hipLaunchKernelGGL(pw_wgrad_reduce_kernel, dim3(cdiv(K * C, 256)), dim3(256), 0, as_stream(stream), partial, dw, ns, K, C, kc_layout, accumulate);
+  hipLaunchKernelGGL(pw_wgrad_reduce_kernel, dim3(cdiv(K * C, 32)), dim3(256), 0, as_stream(stream), partial, dw, ns, K, C, kc_layout, accumulate);
   MI_CHECK_LAUNCH("pw_wgrad");
   return MI355_OK;
 }
