@@ -1,0 +1,295 @@
+#!/usr/bin/env python
+"""Domain-adaptive hand-pose training on the MI355X kernels — same command line, log / checkpoint layout and
+training schedule as the reference's ``train1.py`` (main :37-275, pretrain :278-325, train :328-492,
+validate :495-536, CLI :591-675).  Additive flags: ``--synthetic`` (seeded synthetic data instead of the
+out-of-scope CPU dataset layer), ``--dtype {bf16,f32}``, ``--no-graph``.
+
+    python train1.py data/H3D -t Hand3DStudio --synthetic -a resnet50 -b 64
+"""
+import argparse
+import os
+import random
+import shutil
+import sys
+import time
+import warnings
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+if HERE not in sys.path:
+    sys.path.insert(0, HERE)
+
+import torch
+from torch.optim.lr_scheduler import LambdaLR, MultiStepLR
+from torch.utils.data import DataLoader
+
+import mi355
+import uda.model as models
+from mi355.da_step import build_training
+from mi355.optim import FusedSGD
+from uda.model.loss import JointsKLLoss
+from uda.model.pose_resnet2 import Upsampling, PoseResNet
+from uda.model.regda_7 import PoseResNetx9 as RegDAPoseResNetx1, PoseResNetx10 as RegDAPoseResNetx2
+from utils.data import ForeverDataIterator
+from utils.keypoint_detection import accuracy
+from utils.logger import CompleteLogger
+from utils.meter import AverageMeter, ProgressMeter, AverageMeterDict
+
+device = torch.device("cuda" if torch.cuda.is_available() else "cpu")
+
+
+def build_datasets(args):
+    image_size, heatmap_size = (args.image_size,) * 2, (args.heatmap_size,) * 2
+    if args.synthetic:
+        from utils.synthetic_dataset import SyntheticHand21
+        mk = lambda n, seed: SyntheticHand21(n, image_size, heatmap_size, seed=seed)
+        n = args.batch_size * max(args.iters_per_epoch, 1)
+        return mk(n, 11), mk(4 * args.batch_size, 12), mk(n, 13), mk(4 * args.batch_size, 14)
+    try:
+        import uda.dataset as datasets               # the reference's CPU dataset layer, if the user supplies it
+        import uda.dataset.keypoint_detection as T
+    except ImportError as e:
+        raise SystemExit('The CPU dataset / augmentation layer (uda.dataset, PIL+cv2+torchvision) is out of scope of '
+                         'this build: run with --synthetic, or put the reference\'s uda/dataset package on PYTHONPATH '
+                         '(%s)' % e)
+    normalize = T.Normalize([0.485, 0.456, 0.406], [0.229, 0.224, 0.225])
+    train_tf = T.Compose([T.RandomRotation(args.rotation), T.RandomResizedCrop(size=args.image_size, scale=args.resize_scale),
+                          T.ColorJitter(brightness=0.25, contrast=0.25, saturation=0.25), T.GaussianBlur(), T.ToTensor(), normalize])
+    val_tf = T.Compose([T.Resize(args.image_size), T.ToTensor(), normalize])
+    src, tgt = datasets.__dict__[args.source], datasets.__dict__[args.target]
+    kw = dict(image_size=image_size, heatmap_size=heatmap_size)
+    return (src(root=args.source_root, transforms=train_tf, **kw), src(root=args.source_root, split='test', transforms=val_tf, **kw),
+            tgt(root=args.target_root, transforms=train_tf, **kw), tgt(root=args.target_root, split='test', transforms=val_tf, **kw))
+
+
+def main(args):
+    logger = CompleteLogger(args.log, args.phase)
+    print(args)
+    if device.type != 'cuda':
+        raise SystemExit('this training path needs an MI355X (HIP kernels only, no CPU fallback)')
+    mi355.load()
+    mi355.set_compute_dtype(args.dtype)
+    if args.seed is not None:
+        random.seed(args.seed)
+        torch.manual_seed(args.seed)
+        warnings.warn('You have chosen to seed training.')
+
+    train_s, val_s, train_t, val_t = build_datasets(args)
+    ld = lambda ds, train: DataLoader(ds, batch_size=args.batch_size, shuffle=train, num_workers=args.workers if train else 0,
+                                      pin_memory=True, drop_last=train)
+    train_source_loader, val_source_loader = ld(train_s, True), ld(val_s, False)
+    train_target_loader, val_target_loader = ld(train_t, True), ld(val_t, False)
+    print("Source train:", len(train_source_loader)); print("Target train:", len(train_target_loader))
+    print("Source test:", len(val_source_loader)); print("Target test:", len(val_target_loader))
+    train_source_iter, train_target_iter = ForeverDataIterator(train_source_loader), ForeverDataIterator(train_target_loader)
+
+    # model (+ the frozen EMA copy the reference builds and checkpoints, train1.py:102-128)
+    backbone = models.__dict__[args.arch](pretrained=True)
+    upsampling = Upsampling(backbone.out_features)
+    num_keypoints = train_s.num_keypoints
+    model = RegDAPoseResNetx1(backbone, upsampling, 256, num_keypoints, num_head_layers=args.num_head_layers, finetune=True).to(device)
+    ema_bb = models.__dict__[args.arch](pretrained=False)
+    model_ema = RegDAPoseResNetx2(ema_bb, Upsampling(ema_bb.out_features), 256, num_keypoints,
+                                  num_head_layers=args.num_head_layers, finetune=True).to(device)
+    for p_main, p_ema in zip(model.parameters(), model_ema.parameters()):
+        p_ema.data.copy_(p_main.data)
+        p_ema.requires_grad = False
+
+    criterion = JointsKLLoss()
+    step, opts, scheds = build_training(model, heatmap_size=args.heatmap_size, lr=args.lr, momentum=args.momentum, wd=args.wd,
+                                        lr_gamma=args.lr_gamma, lr_decay=args.lr_decay, trade_off=args.trade_off,
+                                        num_keypoints=num_keypoints)
+    start_epoch = 0
+    if args.resume is None:
+        if args.pretrain is None or (args.synthetic and not os.path.exists(args.pretrain)):
+            print("Pretraining the model on source domain.")
+            args.pretrain = logger.get_checkpoint_path('pretrain')
+            pre = PoseResNet(backbone, upsampling, 256, num_keypoints, True).to(device)
+            optimizer = FusedSGD(pre.get_parameters(lr=args.lr), lr=args.lr, momentum=args.momentum, weight_decay=args.wd, nesterov=True)
+            lr_scheduler = MultiStepLR(optimizer, args.lr_step, args.lr_factor)
+            best_acc = -1
+            for epoch in range(args.pretrain_epochs):
+                lr_scheduler.step()                      # the reference steps the schedule before the epoch (train1.py:167)
+                pretrain(train_source_iter, pre, criterion, optimizer, epoch, args)
+                acc = validate(val_source_loader, pre, criterion, args)
+                if acc['all'] > best_acc:
+                    best_acc = acc['all']
+                    torch.save({'model': pre.state_dict()}, args.pretrain)
+                print("Source: {} best: {}".format(acc['all'], best_acc))
+        pretrained_dict = torch.load(args.pretrain, map_location='cpu', weights_only=False)['model']
+        model_dict = model.state_dict()
+        pretrained_dict = {k: v for k, v in pretrained_dict.items() if k in model_dict}
+        model.load_state_dict(pretrained_dict, strict=False)
+        model_ema.load_state_dict(pretrained_dict, strict=False)
+    else:
+        ck = torch.load(args.resume, map_location='cpu', weights_only=False)
+        model.load_state_dict(ck['model']); model_ema.load_state_dict(ck['model'])
+        for k, name in (('f', 'optimizer_f'), ('h', 'optimizer_h'), ('h_adv', 'optimizer_h_adv')):
+            opts[k].load_state_dict(ck[name]); scheds[k].load_state_dict(ck['lr_scheduler' + name[len('optimizer'):]])
+        for k in ('h_adv2', 'h_adv3'):                    # additive keys (the reference never saved these two)
+            if 'optimizer_' + k in ck:
+                opts[k].load_state_dict(ck['optimizer_' + k]); scheds[k].load_state_dict(ck['lr_scheduler_' + k])
+        model.gl_layer.iter_num = ck.get('gl_iter_num', 0)
+        start_epoch = ck['epoch'] + 1
+
+    if args.phase == 'test':
+        s_acc = validate(val_source_loader, model, criterion, args)
+        t_acc = validate(val_target_loader, model, criterion, args)
+        print("Source: {:4.3f} Target: {:4.3f}".format(s_acc['all'], t_acc['all']))
+        for name, acc in t_acc.items():
+            print("{}: {:4.3f}".format(name, acc))
+        logger.close()
+        return
+
+    best_acc = 0
+    print("Start regression domain adaptation.")
+    for epoch in range(start_epoch, args.epochs):
+        logger.set_epoch(epoch)
+        print(*[scheds[k].get_last_lr() for k in ('f', 'h', 'h_adv', 'h_adv2')])
+        train(train_source_iter, train_target_iter, step, scheds, epoch, args)
+        s_acc = validate(val_source_loader, model, criterion, args)
+        t_acc = validate(val_target_loader, model, criterion, args)
+        torch.save({'model': model.state_dict(),
+                    'optimizer_f': opts['f'].state_dict(), 'optimizer_h': opts['h'].state_dict(),
+                    'optimizer_h_adv': opts['h_adv'].state_dict(),
+                    'lr_scheduler_f': scheds['f'].state_dict(), 'lr_scheduler_h': scheds['h'].state_dict(),
+                    'lr_scheduler_h_adv': scheds['h_adv'].state_dict(), 'epoch': epoch, 'args': args,
+                    # additive keys: close the reference's resume gaps
+                    'optimizer_h_adv2': opts['h_adv2'].state_dict(), 'optimizer_h_adv3': opts['h_adv3'].state_dict(),
+                    'lr_scheduler_h_adv2': scheds['h_adv2'].state_dict(), 'lr_scheduler_h_adv3': scheds['h_adv3'].state_dict(),
+                    'gl_iter_num': model.gl_layer.iter_num}, logger.get_checkpoint_path(epoch))
+        torch.save({'model_ema': model_ema.state_dict()}, logger.get_checkpoint_path('model_ema'))
+        if t_acc['all'] > best_acc:
+            shutil.copy(logger.get_checkpoint_path(epoch), logger.get_checkpoint_path('best'))
+            best_acc = t_acc['all']
+        print("Source: {:4.3f} Target: {:4.3f} Target(best): {:4.3f}".format(s_acc['all'], t_acc['all'], best_acc))
+        for name, acc in t_acc.items():
+            print("{}: {:4.3f}".format(name, acc))
+    logger.close()
+
+
+def pretrain(train_source_iter, model, criterion, optimizer, epoch, args):
+    batch_time, data_time = AverageMeter('Time', ':4.2f'), AverageMeter('Data', ':3.1f')
+    losses_s, acc_s = AverageMeter('Loss (s)', ":.2e"), AverageMeter("Acc (s)", ":3.2f")
+    progress = ProgressMeter(args.iters_per_epoch, [batch_time, data_time, losses_s, acc_s], prefix="Epoch: [{}]".format(epoch))
+    model.train()
+    end = time.time()
+    for i in range(args.iters_per_epoch):
+        optimizer.zero_grad()
+        x_s, label_s, weight_s, _ = next(train_source_iter)
+        x_s, label_s, weight_s = x_s.to(device, non_blocking=True), label_s.to(device, non_blocking=True), weight_s.to(device, non_blocking=True)
+        data_time.update(time.time() - end)
+        y_s = model(x_s)
+        loss_s = criterion(y_s, label_s, weight_s)
+        loss_s.backward()
+        optimizer.step()
+        if i % args.print_freq == 0:                    # host reads only when something is printed
+            _, avg_acc_s, cnt_s, _ = accuracy(y_s.detach(), label_s)
+            acc_s.update(avg_acc_s, cnt_s); losses_s.update(float(loss_s), cnt_s)
+            batch_time.update(time.time() - end)
+            progress.display(i)
+        end = time.time()
+
+
+def _pck(dists, thr=0.5):
+    """avg accuracy + count from a (B,K) device tensor of PCK distances (-1 = ignored), utils/keypoint_detection.py:53-92."""
+    d = dists.t().cpu().numpy()
+    accs = [float((row[row != -1] < thr).mean()) for row in d if (row != -1).any()]
+    return (sum(accs) / len(accs) if accs else 0), len(accs)
+
+
+def train(train_source_iter, train_target_iter, step, scheds, epoch, args):
+    names = ['Time', 'Data', 'Loss (s)', 'Loss (t, false)', 'Loss (t, truth)', 'Acc (s)', 'Acc (t)', 'Acc (s, adv)', 'Acc (t, adv)']
+    fmts = [':4.2f', ':3.1f', ':.2e', ':.2e', ':.2e', ':3.2f', ':3.2f', ':3.2f', ':3.2f']
+    meters = [AverageMeter(n, f) for n, f in zip(names, fmts)]
+    progress = ProgressMeter(args.iters_per_epoch, meters, prefix="Epoch: [{}]".format(epoch))
+    end = time.time()
+    for i in range(args.iters_per_epoch):
+        x_s, label_s, weight_s, _ = next(train_source_iter)
+        x_t, label_t, weight_t, _ = next(train_target_iter)
+        to = lambda t: t.to(device, non_blocking=True)
+        batch = dict(x_s=to(x_s), label_s=to(label_s), w_s=to(weight_s), x_t=to(x_t), w_t=to(weight_t), label_t=to(label_t))
+        meters[1].update(time.time() - end)
+        if not args.no_graph and step.graphs is None and (epoch, i) == (0, 3):
+            step.capture(batch, warmup=0)
+        out = step.run(batch)                            # steps A, B, C + GL step (train1.py:371-453)
+        for s in scheds.values():
+            s.step()
+        if i % args.print_freq == 0:
+            for m, k in zip(meters[2:5], ('loss_s', 'loss_gf', 'loss_gt')):
+                m.update(float(out[k]), args.batch_size)
+            for m, k in zip(meters[5:], ('pck_s', 'pck_t', 'pck_s_adv', 'pck_t_adv')):
+                a, c = _pck(out[k]); m.update(a, c)
+            meters[0].update(time.time() - end)
+            progress.display(i)
+        end = time.time()
+
+
+def validate(val_loader, model, criterion, args):
+    batch_time, losses = AverageMeter('Time', ':6.3f'), AverageMeter('Loss', ':.2e')
+    acc = AverageMeterDict(val_loader.dataset.keypoints_group.keys(), ":3.2f")
+    progress = ProgressMeter(len(val_loader), [batch_time, losses, acc['all']], prefix='Test: ')
+    model.eval()
+    with torch.no_grad():
+        end = time.time()
+        for i, (x, label, weight, meta) in enumerate(val_loader):
+            x, label, weight = x.to(device), label.to(device), weight.to(device)
+            y = model(x)
+            loss = criterion(y, label, weight)
+            losses.update(loss.item(), x.size(0))
+            acc_per_points, avg_acc, cnt, pred = accuracy(y, label)
+            acc.update(val_loader.dataset.group_accuracy(acc_per_points), x.size(0))
+            batch_time.update(time.time() - end)
+            end = time.time()
+            if i % args.print_freq == 0:
+                progress.display(i)
+    return acc.average()
+
+
+def build_parser(description='Source Only for Keypoint Detection Domain Adaptation'):
+    arch_names = sorted(n for n in models.__dict__ if n.islower() and not n.startswith("__") and callable(models.__dict__[n]))
+    p = argparse.ArgumentParser(description=description)
+    a = p.add_argument
+    a('--source_root', default='data/RHD', help='root path of the source dataset')
+    a('target_root', help='root path of the target dataset')
+    a('-s', '--source', default='RenderedHandPose', help='source domain(s)')
+    a('-t', '--target', help='target domain(s)')
+    a('--resize-scale', nargs='+', type=float, default=(0.6, 1.3), help='scale range for the RandomResizeCrop augmentation')
+    a('--rotation', type=int, default=180, help='rotation range of the RandomRotation augmentation')
+    a('--image-size', type=int, default=256, help='input image size')
+    a('--heatmap-size', type=int, default=64, help='output heatmap size')
+    a('-a', '--arch', metavar='ARCH', default='resnet101', choices=arch_names, help='backbone architecture: ' + ' | '.join(arch_names))
+    a('-a2', '--arch2', metavar='ARCH', default='net_hg', help='(unused, kept for CLI parity)')
+    a("--pretrain", type=str, default='models/pretrain_rhd.pth', help="Where restore pretrained model parameters from.")
+    a("--ema_model", type=str, default=None, help="(unused, kept for CLI parity)")
+    a("--resume", type=str, default=None, help="where restore model parameters from.")
+    a("--resume2", type=str, default=None, help="(unused, kept for CLI parity)")
+    a('--num-head-layers', type=int, default=2)
+    a('--margin', type=float, default=4., help="margin gamma (unused, kept for CLI parity)")
+    a('--trade-off', default=1., type=float, help='the trade-off hyper-parameter for transfer loss')
+    a('-b', '--batch-size', default=32, type=int, metavar='N', help='mini-batch size (default: 32)')
+    a('--lr', '--learning-rate', default=0.01, type=float, metavar='LR', help='initial learning rate', dest='lr')
+    a('--momentum', default=0.9, type=float, metavar='M', help='momentum')
+    a('--wd', '--weight-decay', default=0.0001, type=float, metavar='W', help='weight decay (default: 1e-4)')
+    a('--lr-gamma', default=0.0001, type=float)
+    a('--lr-decay', default=0.75, type=float, help='parameter for lr scheduler')
+    a('--lr-step', default=[45, 60], type=tuple, help='parameter for lr scheduler')
+    a('--lr-factor', default=0.1, type=float, help='parameter for lr scheduler')
+    a('-j', '--workers', default=4, type=int, metavar='N', help='number of data loading workers (default: 4)')
+    a('--pretrain_epochs', default=70, type=int, metavar='N', help='number of total epochs to run')
+    a('--epochs', default=200, type=int, metavar='N', help='number of total epochs to run')
+    a('-i', '--iters-per-epoch', default=500, type=int, help='Number of iterations per epoch')
+    a('-p', '--print-freq', default=100, type=int, metavar='N', help='print frequency (default: 100)')
+    a('--seed', default=1, type=int, help='seed for initializing training. ')
+    a("--log", type=str, default='logs/mt', help="Where to save logs, checkpoints and debugging images.")
+    a("--phase", type=str, default='train', choices=['train', 'test'], help="When phase is 'test', only test the model.")
+    a('--debug', action="store_true", help='(visualisation is out of scope; accepted for CLI parity)')
+    a('--ema-decay', default=0.999, type=float, metavar='ALPHA', help='(unused, kept for CLI parity)')
+    # additive flags
+    a('--synthetic', action='store_true', help='seeded synthetic batches instead of the CPU dataset layer')
+    a('--dtype', default='bf16', choices=['bf16', 'f32'], help='compute dtype of activations / packed weights')
+    a('--no-graph', action='store_true', help='launch kernels eagerly instead of replaying HIP graphs')
+    return p
+
+
+if __name__ == '__main__':
+    main(build_parser().parse_args())
