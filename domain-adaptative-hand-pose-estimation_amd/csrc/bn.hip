@@ -90,12 +90,21 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
   const int c = blockIdx.x * 8 + cl;
   if (blockIdx.x == 0 && threadIdx.x == 0 && nbt) *nbt += 1;
   float n = 0.f, mean = 0.f, m2 = 0.f;
-  if (c < C)
-    for (int s = lane; s < nslices; s += 32) {
-      const float* q = partial + ((size_t)s * C + c) * 3;
-      const float nb = q[0];
-      if (nb > 0.f) { const float nt = n + nb, f = nb / nt, d = q[1] - mean; mean += d * f; m2 += q[2] + d * d * n * f; n = nt; }
+  if (c < C) {
+    // nslices <= 1024 -> at most 32 slices per lane: load them all (independent loads in flight), then fold in order
+    float qn[32], qm[32], qv[32];
+#pragma unroll
+    for (int j = 0; j < 32; ++j) {
+      const int s = lane + 32 * j;
+      if (s < nslices) { const float* q = partial + ((size_t)s * C + c) * 3; qn[j] = q[0]; qm[j] = q[1]; qv[j] = q[2]; }
+      else { qn[j] = 0.f; qm[j] = 0.f; qv[j] = 0.f; }
     }
+#pragma unroll
+    for (int j = 0; j < 32; ++j) {
+      const float nb = qn[j];
+      if (nb > 0.f) { const float nt = n + nb, f = nb / nt, d = qm[j] - mean; mean += d * f; m2 += qv[j] + d * d * n * f; n = nt; }
+    }
+  }
   sn[threadIdx.x] = n; sm[threadIdx.x] = mean; sv[threadIdx.x] = m2;
   __syncthreads();
   if (lane != 0 || c >= C) return;
@@ -204,8 +213,16 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
   const int cl = threadIdx.x & 7, lane = threadIdx.x >> 3;
   const int c = blockIdx.x * 8 + cl;
   float s1 = 0.f, s2 = 0.f;
-  if (c < C)
-    for (int s = lane; s < nslices; s += 32) { const float* q = partial + ((size_t)s * C + c) * 2; s1 += q[0]; s2 += q[1]; }
+  if (c < C) {
+    float q1[32], q2[32];
+#pragma unroll
+    for (int j = 0; j < 32; ++j) {
+      const int s = lane + 32 * j;
+      if (s < nslices) { const float* q = partial + ((size_t)s * C + c) * 2; q1[j] = q[0]; q2[j] = q[1]; } else { q1[j] = 0.f; q2[j] = 0.f; }
+    }
+#pragma unroll
+    for (int j = 0; j < 32; ++j) { s1 += q1[j]; s2 += q2[j]; }
+  }
   a1[threadIdx.x] = s1; a2[threadIdx.x] = s2;
   __syncthreads();
   if (lane != 0 || c >= C) return;
