@@ -23,6 +23,7 @@ struct GatherArgs {
   int M;
   int accumulate;
   int ntm, ntn;
+  unsigned a_bytes, b_bytes;
   Tap taps[MAX_TAPS];
 };
 
@@ -34,6 +35,18 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
   int q = nblk >> 3, r = nblk & 7, x = bid & 7, i = bid >> 3;
   int start = (x < r) ? x * (q + 1) : r * (q + 1) + (x - r) * q;
   return start + i;
+}
+
+// 16-byte load through a buffer descriptor: out-of-range offsets (>= num_records) return zeros, so halo / tail
+// handling needs no branch and no zero-initialised destination.
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
+#define OOB_OFF ((int)0x80000000)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ uint4 buf_load16(__amdgpu_buffer_rsrc_t rs, int byte_off) {
+  u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(rs, byte_off, 0, 0);
+  return make_uint4(v[0], v[1], v[2], v[3]);
 }
 
 template <typename T> struct MmaTraits;
@@ -65,8 +78,7 @@ __global__ __launch_bounds__(256) void gather_gemm_kernel(const GatherArgs p) {
   const int wm0 = (wave >> 1) * WM, wn0 = (wave & 1) * WN;
   const int lc = t & 7, lr = t >> 3;
 
-  const T* __restrict__ A = reinterpret_cast<const T*>(p.A);
-  const T* __restrict__ B = reinterpret_cast<const T*>(p.B);
+  const __amdgpu_buffer_rsrc_t rsA = make_rsrc(p.A, p.a_bytes), rsB = make_rsrc(p.B, p.b_bytes);
 
   // decode this thread's A rows once
   int iy0[RA], ix0[RA], abase[RA];
@@ -103,14 +115,12 @@ __global__ __launch_bounds__(256) void gather_gemm_kernel(const GatherArgs p) {
     for (int i = 0; i < RA; ++i) {
       int iy = iy0[i] + tp.dy, ix = ix0[i] + tp.dx;
       bool ok = okq && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
-      ra[i] = make_uint4(0, 0, 0, 0);
-      if (ok) ra[i] = *reinterpret_cast<const uint4*>(A + ((size_t)(abase[i] + iy * p.Wi + ix) * p.Ci + cc));
+      ra[i] = buf_load16(rsA, ok ? ((abase[i] + iy * p.Wi + ix) * p.Ci + cc) * (int)sizeof(T) : OOB_OFF);
     }
 #pragma unroll
     for (int i = 0; i < RB; ++i) {
       int n = n0 + lr + 32 * i;
-      rb[i] = make_uint4(0, 0, 0, 0);
-      if (okq && n < p.Nout) rb[i] = *reinterpret_cast<const uint4*>(B + ((size_t)n * p.ldb + koff));
+      rb[i] = buf_load16(rsB, (okq && n < p.Nout) ? (n * p.ldb + koff) * (int)sizeof(T) : OOB_OFF);
     }
   };
   char* const as = smem;
@@ -229,6 +239,7 @@ struct WgradArgs {
   int M, rows_per_split, ldw;
   long slab_stride;
   int nto, nti;
+  unsigned x_bytes, dy_bytes;
   FastDiv dWo, dHo;
 };
 
@@ -252,8 +263,7 @@ __global__ __launch_bounds__(256) void wgrad_gemm_kernel(const WgradArgs p) {
   const int wm0 = (wave >> 1) * 64, wn0 = (wave & 1) * 64;
   const int lc = t % CPR, lr = t / CPR;
 
-  const T* __restrict__ X = reinterpret_cast<const T*>(p.X);
-  const T* __restrict__ DY = reinterpret_cast<const T*>(p.DY);
+  const __amdgpu_buffer_rsrc_t rsX = make_rsrc(p.X, p.x_bytes), rsY = make_rsrc(p.DY, p.dy_bytes);
 
   // this thread's fixed column chunk -> (tap, ci)
   const int col = c0 + lc * CH;
@@ -272,17 +282,13 @@ __global__ __launch_bounds__(256) void wgrad_gemm_kernel(const WgradArgs p) {
 #pragma unroll
     for (int i = 0; i < RPT; ++i) {
       const int m = mt0 + lr + (256 / CPR) * i;
-      rx[i] = make_uint4(0, 0, 0, 0); ry[i] = make_uint4(0, 0, 0, 0);
-      if (m < mend) {
-        if (ook) ry[i] = *reinterpret_cast<const uint4*>(DY + ((size_t)m * p.Co + o0 + lc * CH));
-        if (colok) {
-          unsigned r = fd_div((unsigned)m, p.dWo); int ox = m - r * p.Wo;
-          unsigned n = fd_div(r, p.dHo); int oy = r - n * p.Ho;
-          int iy = oy * p.stride + tdy, ix = ox * p.stride + tdx;
-          if ((unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi)
-            rx[i] = *reinterpret_cast<const uint4*>(X + (((size_t)n * p.Hi + iy) * p.Wi + ix) * p.Ci + ci);
-        }
-      }
+      const bool mok = m < mend;
+      ry[i] = buf_load16(rsY, (mok && ook) ? (m * p.Co + o0 + lc * CH) * (int)sizeof(T) : OOB_OFF);
+      unsigned r = fd_div((unsigned)m, p.dWo); int ox = m - r * p.Wo;
+      unsigned n = fd_div(r, p.dHo); int oy = r - n * p.Ho;
+      int iy = oy * p.stride + tdy, ix = ox * p.stride + tdx;
+      const bool xok = mok && colok && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
+      rx[i] = buf_load16(rsX, xok ? (((int)n * p.Hi + iy) * p.Wi + ix) * p.Ci * (int)sizeof(T) + ci * (int)sizeof(T) : OOB_OFF);
     }
   };
   auto store_tile = [&]() {
@@ -410,6 +416,12 @@ static int dispatch_gather(GatherArgs& a, hipStream_t st) {
   if (a.cshift < 0) MI_FAIL(MI355_EINVAL, "gather: Ci/%d must be a power of two (Ci=%d)", CH, a.Ci);
   if (a.Nout % CH) MI_FAIL(MI355_EINVAL, "gather: Nout=%d not a multiple of %d", a.Nout, CH);
   a.kchunks = a.ntaps << a.cshift;
+  {
+    // A spans [images][Hi][Wi][Ci]; images = M / (OHp*OWp)
+    const long imgs = a.M / ((long)a.OHp * a.OWp);
+    a.a_bytes = (unsigned)(imgs * a.Hi * a.Wi * a.Ci * (long)sizeof(T));
+    a.b_bytes = (unsigned)((long)a.Nout * a.ldb * (long)sizeof(T));
+  }
   const bool small = (a.Ci / CH) < 8;
   double flops = 2.0 * a.M * (double)a.Nout * a.ntaps * a.Ci;
   ProfScope ps(st, flops);
@@ -543,6 +555,7 @@ extern "C" int mi355_conv_wgrad(const mi355_conv_desc* d, const void* x, const v
   a.M = d->N * d->Ho * d->Wo; a.rows_per_split = w.rows_per_split; a.ldw = w.ldw;
   a.slab_stride = (long)d->Co * w.ldw; a.nto = w.nto; a.nti = w.nti;
   a.dWo = make_fastdiv(d->Wo); a.dHo = make_fastdiv(d->Ho);
+  { const long esz = d->dtype == MI355_BF16 ? 2 : 4; a.x_bytes = (unsigned)((long)d->N * d->Hi * d->Wi * d->Ci * esz); a.dy_bytes = (unsigned)((long)a.M * d->Co * esz); }
   {
     ProfScope ps(st, 2.0 * a.M * (double)d->Co * w.ldw);
     dim3 grid(w.nto * w.nti, 1, w.S);
