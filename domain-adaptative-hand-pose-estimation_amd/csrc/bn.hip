@@ -78,40 +78,36 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const T* __restrict__ x, 
   }
 }
 
-// 256-thread block = 8 channels x 32 slice-lanes: each lane folds its slices (s = lane, lane+32, ...) with Chan's
-// update, lanes are folded in lane order through LDS (fixed order -> bitwise reproducible), then lane 0 updates the
-// running statistics and emits scale/shift.
+// One wave per channel (4 channels per 256-thread block): lane l folds slices l, l+64, ... (<= 16 of them, all loads
+// issued up front), then a shuffle-down tree folds the 64 lanes (lower lane = left operand, so the order is fixed and
+// the result bitwise reproducible); lane 0 updates the running statistics and emits scale/shift.
+__device__ __forceinline__ void chan_combine(float& n, float& mean, float& m2, float nb, float mb, float vb) {
+  if (nb > 0.f) { const float nt = n + nb, f = nb / nt, d = mb - mean; mean += d * f; m2 += vb + d * d * n * f; n = nt; }
+}
 __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ partial, int nslices, int C, const float* __restrict__ gamma,
                                    const float* __restrict__ beta, float* running_mean, float* running_var,
                                    int64_t* nbt, float* save_mean, float* save_invstd, float* scale_shift, float eps,
                                    float momentum) {
-  __shared__ float sn[256], sm[256], sv[256];
-  const int cl = threadIdx.x & 7, lane = threadIdx.x >> 3;
-  const int c = blockIdx.x * 8 + cl;
+  const int lane = threadIdx.x & 63;
+  const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (blockIdx.x == 0 && threadIdx.x == 0 && nbt) *nbt += 1;
+  if (c >= C) return;                      // wave-uniform
+  float qn[16], qm[16], qv[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    const int s = lane + 64 * j;
+    if (s < nslices) { const float* q = partial + ((size_t)s * C + c) * 3; qn[j] = q[0]; qm[j] = q[1]; qv[j] = q[2]; }
+    else { qn[j] = 0.f; qm[j] = 0.f; qv[j] = 0.f; }
+  }
   float n = 0.f, mean = 0.f, m2 = 0.f;
-  if (c < C) {
-    // nslices <= 1024 -> at most 32 slices per lane: load them all (independent loads in flight), then fold in order
-    float qn[32], qm[32], qv[32];
 #pragma unroll
-    for (int j = 0; j < 32; ++j) {
-      const int s = lane + 32 * j;
-      if (s < nslices) { const float* q = partial + ((size_t)s * C + c) * 3; qn[j] = q[0]; qm[j] = q[1]; qv[j] = q[2]; }
-      else { qn[j] = 0.f; qm[j] = 0.f; qv[j] = 0.f; }
-    }
+  for (int j = 0; j < 16; ++j) chan_combine(n, mean, m2, qn[j], qm[j], qv[j]);
 #pragma unroll
-    for (int j = 0; j < 32; ++j) {
-      const float nb = qn[j];
-      if (nb > 0.f) { const float nt = n + nb, f = nb / nt, d = qm[j] - mean; mean += d * f; m2 += qv[j] + d * d * n * f; n = nt; }
-    }
+  for (int o = 32; o > 0; o >>= 1) {
+    const float nb = __shfl_down(n, o, 64), mb = __shfl_down(mean, o, 64), vb = __shfl_down(m2, o, 64);
+    chan_combine(n, mean, m2, nb, mb, vb);
   }
-  sn[threadIdx.x] = n; sm[threadIdx.x] = mean; sv[threadIdx.x] = m2;
-  __syncthreads();
-  if (lane != 0 || c >= C) return;
-  for (int l = 1; l < 32; ++l) {
-    const int o = l * 8 + cl; const float nb = sn[o];
-    if (nb > 0.f) { const float nt = n + nb, f = nb / nt, d = sm[o] - mean; mean += d * f; m2 += sv[o] + d * d * n * f; n = nt; }
-  }
+  if (lane != 0) return;
   const float var = m2 / n;
   const float invstd = 1.0f / sqrtf(var + eps);
   save_mean[c] = mean; save_invstd[c] = invstd;
@@ -205,28 +201,25 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
 }
 
 // coeff[c] = (k0 = gamma*invstd, k1 = mean(dy_eff), k2 = mean(dy_eff*xhat)); dgamma/dbeta (=|+=)
-// block = 8 channels x 32 slice-lanes, folded in a fixed order (see bn_finalize_kernel)
+// one wave per channel, fixed-order shuffle tree (see bn_finalize_kernel)
 __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ partial, int nslices, int C, float inv_rows,
                                        const float* __restrict__ gamma, const float* __restrict__ invstd, float* dgamma,
                                        float* dbeta, int accumulate, float* coeff) {
-  __shared__ float a1[256], a2[256];
-  const int cl = threadIdx.x & 7, lane = threadIdx.x >> 3;
-  const int c = blockIdx.x * 8 + cl;
-  float s1 = 0.f, s2 = 0.f;
-  if (c < C) {
-    float q1[32], q2[32];
+  const int lane = threadIdx.x & 63;
+  const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (c >= C) return;
+  float q1[16], q2[16];
 #pragma unroll
-    for (int j = 0; j < 32; ++j) {
-      const int s = lane + 32 * j;
-      if (s < nslices) { const float* q = partial + ((size_t)s * C + c) * 2; q1[j] = q[0]; q2[j] = q[1]; } else { q1[j] = 0.f; q2[j] = 0.f; }
-    }
-#pragma unroll
-    for (int j = 0; j < 32; ++j) { s1 += q1[j]; s2 += q2[j]; }
+  for (int j = 0; j < 16; ++j) {
+    const int s = lane + 64 * j;
+    if (s < nslices) { const float* q = partial + ((size_t)s * C + c) * 2; q1[j] = q[0]; q2[j] = q[1]; } else { q1[j] = 0.f; q2[j] = 0.f; }
   }
-  a1[threadIdx.x] = s1; a2[threadIdx.x] = s2;
-  __syncthreads();
-  if (lane != 0 || c >= C) return;
-  for (int l = 1; l < 32; ++l) { s1 += a1[l * 8 + cl]; s2 += a2[l * 8 + cl]; }
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) { s1 += q1[j]; s2 += q2[j]; }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { s1 += __shfl_down(s1, o, 64); s2 += __shfl_down(s2, o, 64); }
+  if (lane != 0) return;
   if (dbeta) dbeta[c] = (accumulate ? dbeta[c] : 0.f) + s1;
   if (dgamma) dgamma[c] = (accumulate ? dgamma[c] : 0.f) + s2;
   if (coeff) { coeff[c] = gamma[c] * invstd[c]; coeff[C + c] = s1 * inv_rows; coeff[2 * C + c] = s2 * inv_rows; }
@@ -262,17 +255,18 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
 }
 
 __global__ __launch_bounds__(256) void colsum_finalize_kernel(const float* __restrict__ partial, int nslices, int C, float* out, int accumulate) {
-  __shared__ float a1[256];
-  const int cl = threadIdx.x & 7, lane = threadIdx.x >> 3;
-  const int c = blockIdx.x * 8 + cl;
+  const int lane = threadIdx.x & 63;
+  const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (c >= C) return;
+  float q[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) { const int i = lane + 64 * j; q[j] = (i < nslices) ? partial[((size_t)i * C + c) * 2] : 0.f; }
   float s = 0.f;
-  if (c < C)
-    for (int i = lane; i < nslices; i += 32) s += partial[((size_t)i * C + c) * 2];
-  a1[threadIdx.x] = s;
-  __syncthreads();
-  if (lane != 0 || c >= C) return;
-  for (int l = 1; l < 32; ++l) s += a1[l * 8 + cl];
-  out[c] = (accumulate ? out[c] : 0.f) + s;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) s += q[j];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+  if (lane == 0) out[c] = (accumulate ? out[c] : 0.f) + s;
 }
 
 // -------------------------------------------------------------------------------- host
@@ -302,7 +296,7 @@ extern "C" int mi355_bn_train_fwd(const void* x, const void* residual, void* y, 
   dim3 g(p.colgroups, p.nslices);
   if (dtype == MI355_BF16) hipLaunchKernelGGL(bn_stats_kernel<bf16_t>, g, dim3(256), 0, st, (const bf16_t*)x, partial, rows, C, p.TX, p.rows_per_slice);
   else hipLaunchKernelGGL(bn_stats_kernel<float>, g, dim3(256), 0, st, (const float*)x, partial, rows, C, p.TX, p.rows_per_slice);
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 8)), dim3(256), 0, st, partial, p.nslices, C, gamma, beta, running_mean, running_var, nbt, save_mean, save_invstd, ss, eps, momentum);
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 4)), dim3(256), 0, st, partial, p.nslices, C, gamma, beta, running_mean, running_var, nbt, save_mean, save_invstd, ss, eps, momentum);
   dim3 ga = apply_grid(p, rows);
   const float* nf = nullptr;
   if (dtype == MI355_BF16) hipLaunchKernelGGL((bn_apply_kernel<bf16_t, false>), ga, dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)residual, (bf16_t*)y, (const float*)ss, nf, nf, nf, nf, eps, rows, C, p.TX, relu);
@@ -338,7 +332,7 @@ extern "C" int mi355_bn_bwd(const void* dy, const void* x, const void* y, const 
   dim3 g(p.colgroups, p.nslices);
   if (dtype == MI355_BF16) hipLaunchKernelGGL((bn_bwd_reduce_kernel<bf16_t, true>), g, dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)x, (const bf16_t*)y, save_mean, save_invstd, partial, rows, C, p.TX, p.rows_per_slice, relu);
   else hipLaunchKernelGGL((bn_bwd_reduce_kernel<float, true>), g, dim3(256), 0, st, (const float*)dy, (const float*)x, (const float*)y, save_mean, save_invstd, partial, rows, C, p.TX, p.rows_per_slice, relu);
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 8)), dim3(256), 0, st, partial, p.nslices, C, 1.0f / (float)rows, gamma, save_invstd, dgamma, dbeta, accumulate, coeff);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 4)), dim3(256), 0, st, partial, p.nslices, C, 1.0f / (float)rows, gamma, save_invstd, dgamma, dbeta, accumulate, coeff);
   dim3 ga = apply_grid(p, rows);
   if (dtype == MI355_BF16) hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, ga, dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)x, (const bf16_t*)y, save_mean, save_invstd, coeff, (bf16_t*)dx, (bf16_t*)dresidual, rows, C, p.TX, relu);
   else hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, ga, dim3(256), 0, st, (const float*)dy, (const float*)x, (const float*)y, save_mean, save_invstd, coeff, (float*)dx, (float*)dresidual, rows, C, p.TX, relu);
@@ -356,7 +350,7 @@ extern "C" int mi355_colsum(const void* dy, float* out, long rows, int C, int dt
   dim3 g(p.colgroups, p.nslices);
   if (dtype == MI355_BF16) hipLaunchKernelGGL((bn_bwd_reduce_kernel<bf16_t, false>), g, dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)nullptr, (const bf16_t*)nullptr, (const float*)nullptr, (const float*)nullptr, partial, rows, C, p.TX, p.rows_per_slice, 0);
   else hipLaunchKernelGGL((bn_bwd_reduce_kernel<float, false>), g, dim3(256), 0, st, (const float*)dy, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, partial, rows, C, p.TX, p.rows_per_slice, 0);
-  hipLaunchKernelGGL(colsum_finalize_kernel, dim3(cdiv(C, 8)), dim3(256), 0, st, partial, p.nslices, C, out, accumulate);
+  hipLaunchKernelGGL(colsum_finalize_kernel, dim3(cdiv(C, 4)), dim3(256), 0, st, partial, p.nslices, C, out, accumulate);
   MI_CHECK_LAUNCH("colsum");
   return MI355_OK;
 }

@@ -62,11 +62,13 @@ struct GatherSmem {
   static constexpr int kBytes = (GATHER_STAGES * kStage > kOut ? GATHER_STAGES * kStage : kOut) + BM * 4;
 };
 
-template <typename T, int BM, int BN, bool SMALL_C>
-__global__ __launch_bounds__(256) void gather_gemm_kernel(const GatherArgs p) {
+// WGM x WGN waves per workgroup (64 lanes each); every wave owns a (BM/WGM) x (BN/WGN) sub-tile.
+template <typename T, int BM, int BN, bool SMALL_C, int WGM = 2, int WGN = 2>
+__global__ __launch_bounds__(64 * WGM * WGN) void gather_gemm_kernel(const GatherArgs p) {
   constexpr int CH = MmaTraits<T>::CH;
-  constexpr int WM = BM / 2, WN = BN / 2, MT = WM / 32, NT = WN / 32;
-  constexpr int RA = BM / 32, RB = BN / 32;
+  constexpr int NTHR = 64 * WGM * WGN, RPP = NTHR / 8;      // rows staged per pass (8 lanes = one 128-byte row)
+  constexpr int WM = BM / WGM, WN = BN / WGN, MT = WM / 32, NT = WN / 32;
+  constexpr int RA = BM / RPP, RB = BN / RPP;
   using SM = GatherSmem<T, BM, BN>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   int* row_off = reinterpret_cast<int*>(smem + SM::kBytes - BM * 4);
@@ -75,7 +77,7 @@ __global__ __launch_bounds__(256) void gather_gemm_kernel(const GatherArgs p) {
   const int nblk = p.ntm * p.ntn;
   const int tile = xcd_remap(blockIdx.x, nblk);
   const int m0 = (tile / p.ntn) * BM, n0 = (tile % p.ntn) * BN;
-  const int wm0 = (wave >> 1) * WM, wn0 = (wave & 1) * WN;
+  const int wm0 = (wave / WGN) * WM, wn0 = (wave % WGN) * WN;
   const int lc = t & 7, lr = t >> 3;
 
   const __amdgpu_buffer_rsrc_t rsA = make_rsrc(p.A, p.a_bytes), rsB = make_rsrc(p.B, p.b_bytes);
@@ -84,7 +86,7 @@ __global__ __launch_bounds__(256) void gather_gemm_kernel(const GatherArgs p) {
   int iy0[RA], ix0[RA], abase[RA];
 #pragma unroll
   for (int i = 0; i < RA; ++i) {
-    int m = m0 + lr + 32 * i;
+    int m = m0 + lr + RPP * i;
     if (m < p.M) {
       int ox = m % p.OWp, r = m / p.OWp, oy = r % p.OHp, n = r / p.OHp;
       iy0[i] = oy * p.in_sy; ix0[i] = ox * p.in_sx; abase[i] = n * p.Hi * p.Wi;
@@ -119,7 +121,7 @@ __global__ __launch_bounds__(256) void gather_gemm_kernel(const GatherArgs p) {
     }
 #pragma unroll
     for (int i = 0; i < RB; ++i) {
-      int n = n0 + lr + 32 * i;
+      int n = n0 + lr + RPP * i;
       rb[i] = buf_load16(rsB, (okq && n < p.Nout) ? (n * p.ldb + koff) * (int)sizeof(T) : OOB_OFF);
     }
   };
@@ -127,9 +129,9 @@ __global__ __launch_bounds__(256) void gather_gemm_kernel(const GatherArgs p) {
   char* const bs = smem + BM * 128;
   auto store_tile = [&](const uint4 (&ra)[RA], const uint4 (&rb)[RB]) {
 #pragma unroll
-    for (int i = 0; i < RA; ++i) *reinterpret_cast<uint4*>(as + swz128(lr + 32 * i, lc)) = ra[i];
+    for (int i = 0; i < RA; ++i) *reinterpret_cast<uint4*>(as + swz128(lr + RPP * i, lc)) = ra[i];
 #pragma unroll
-    for (int i = 0; i < RB; ++i) *reinterpret_cast<uint4*>(bs + swz128(lr + 32 * i, lc)) = rb[i];
+    for (int i = 0; i < RB; ++i) *reinterpret_cast<uint4*>(bs + swz128(lr + RPP * i, lc)) = rb[i];
   };
 
   f32x16_t acc[MT][NT];
@@ -178,7 +180,9 @@ __global__ __launch_bounds__(256) void gather_gemm_kernel(const GatherArgs p) {
   for (int kt = 0; kt < nk; ++kt) {
     __syncthreads(); store_tile(ra0, rb0); __syncthreads();
     if (kt + 1 < nk) load_tile(kt + 1, ra0, rb0);
+    __builtin_amdgcn_s_setprio(1);
     compute();
+    __builtin_amdgcn_s_setprio(0);
   }
   __syncthreads();
 
@@ -213,7 +217,7 @@ __global__ __launch_bounds__(256) void gather_gemm_kernel(const GatherArgs p) {
   constexpr int CPR = BN / CH;  // 16-byte chunks per tile row
   T* __restrict__ D = reinterpret_cast<T*>(p.D);
   const T* __restrict__ R = reinterpret_cast<const T*>(p.residual);
-  for (int id = t; id < BM * CPR; id += 256) {
+  for (int id = t; id < BM * CPR; id += NTHR) {
     const int r = id / CPR, c = id % CPR;
     const int off = row_off[r];
     const int n = n0 + c * CH;
@@ -398,14 +402,14 @@ __global__ void zero_fill_kernel(uint4* __restrict__ p, size_t n16) {
 // ------------------------------------------------------------------------------------ host side
 static int ilog2_exact(int v) { int s = 0; while ((1 << s) < v) ++s; return ((1 << s) == v) ? s : -1; }
 
-template <typename T, int BM, int BN, bool SMALL_C>
+template <typename T, int BM, int BN, bool SMALL_C, int WGM = 2, int WGN = 2>
 static void launch_gather(GatherArgs& a, hipStream_t st) {
   a.ntm = cdiv(a.M, BM); a.ntn = cdiv(a.Nout, BN);
   constexpr int smem = GatherSmem<T, BM, BN>::kBytes;
-  auto kern = gather_gemm_kernel<T, BM, BN, SMALL_C>;
+  auto kern = gather_gemm_kernel<T, BM, BN, SMALL_C, WGM, WGN>;
   static bool attr_set = false;   // raise the dynamic-LDS cap once per instantiation
   if (!attr_set) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem); attr_set = true; }
-  hipLaunchKernelGGL(kern, dim3(a.ntm * a.ntn), dim3(256), smem, st, a);
+  hipLaunchKernelGGL(kern, dim3(a.ntm * a.ntn), dim3(64 * WGM * WGN), smem, st, a);
 }
 
 template <typename T>
@@ -430,7 +434,7 @@ static int dispatch_gather(GatherArgs& a, hipStream_t st) {
     const long t128 = (long)cdiv(a.M, 128) * cdiv(a.Nout, 128);
     if (a.Nout <= 64) {
       if ((long)cdiv(a.M, 128) >= 512) launch_gather<T, 128, 64, false>(a, st); else launch_gather<T, 64, 64, false>(a, st);
-    } else if (t128 >= 512) launch_gather<T, 128, 128, false>(a, st);
+    } else if (t128 >= 512) launch_gather<T, 128, 128, false>(a, st);   // (128x256 tile with 8 waves measured slower: 687 vs 755 TFLOP/s)
     else if ((long)cdiv(a.M, 64) * cdiv(a.Nout, 128) >= 512) launch_gather<T, 64, 128, false>(a, st);
     else launch_gather<T, 64, 64, false>(a, st);
   }

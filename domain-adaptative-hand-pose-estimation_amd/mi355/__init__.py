@@ -135,10 +135,10 @@ def dtype_code(dt):
 _ws = {}
 
 
-def workspace(nbytes, device):
-    """One grow-only scratch buffer per device; all ops are enqueued on the current stream, so reuse is
-    ordered.  Grows outside graph capture only (warm up before capturing)."""
-    key = (device.index if device.index is not None else torch.cuda.current_device())
+def workspace(nbytes, device, tag='main'):
+    """One grow-only scratch buffer per (device, stream role); every op of one role is enqueued on one stream,
+    so reuse is ordered.  Grows outside graph capture only (warm up before capturing)."""
+    key = (device.index if device.index is not None else torch.cuda.current_device(), tag)
     buf = _ws.get(key)
     if buf is None or buf.numel() < nbytes:
         if torch.cuda.is_current_stream_capturing():
@@ -147,3 +147,52 @@ def workspace(nbytes, device):
         buf = torch.empty(size, dtype=torch.uint8, device=device)
         _ws[key] = buf
     return buf
+
+
+# ---------------------------------------------------------------- side stream for weight gradients
+# Weight gradients are off the critical path of a backward pass (only the optimizer reads them), so they are
+# enqueued on a second HIP stream and overlap the dgrad / BatchNorm-backward chain; `join_side()` is the single
+# rendezvous before the optimizer kernels.  Inputs of in-flight side work are kept referenced until the join, so
+# the caching allocator cannot hand their memory to the main stream early (works inside graph capture too: the
+# side stream forks from and rejoins the capturing stream through events).
+import os as _os
+
+_side = {}
+_pending = []
+# measured on MI355X (ResNet-50, B=64): 51.3 ms/iteration without, 52.1 ms with -> off by default
+SIDE_WGRAD = _os.environ.get('MI355_WGRAD_STREAM', '0') != '0'
+
+
+def side_stream(device):
+    key = device.index if device.index is not None else torch.cuda.current_device()
+    st = _side.get(key)
+    if st is None:
+        st = _side[key] = torch.cuda.Stream(device=device)
+    return st
+
+
+class on_side:
+    """with on_side(device, keep=(x, dy)): ...  -> body runs on the side stream, ordered after the work already
+    enqueued on the current stream."""
+
+    def __init__(self, device, keep=()):
+        self.dev, self.keep = device, keep
+
+    def __enter__(self):
+        self.st = side_stream(self.dev)
+        self.st.wait_stream(torch.cuda.current_stream())
+        _pending.append(self.keep)
+        self.ctx = torch.cuda.stream(self.st)
+        self.ctx.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        return self.ctx.__exit__(*exc)
+
+
+def join_side():
+    """Current stream waits for all side-stream work; releases the tensors kept alive for it."""
+    if _pending:
+        for st in _side.values():
+            torch.cuda.current_stream().wait_stream(st)
+        _pending.clear()

@@ -13,6 +13,7 @@ all-reduced (mean) over the default process group between the backward and the o
 import torch
 import torch.distributed as dist
 
+import mi355 as _rt
 from . import ops
 from .nn import mark_grads_fresh
 
@@ -51,6 +52,7 @@ class DAStep:
             4 * c['rd'](y_s, y_s_adv, None, b['w_s'], mode='min') + \
             4 * c['rd1'](y_s, y_s_adv3, b['w_s'], mode='min')
         loss_s.backward()
+        _rt.join_side()
         self.out.update(loss_s=loss_s.detach(), y_s=y_s.detach(), y_s_adv=y_s_adv.detach())
 
     def _update_A(self):
@@ -71,6 +73,7 @@ class DAStep:
         loss3 = to * c['rd2'](y_t, y_t_adv2, target0, b['w_t'], mode='max')
         loss_gf = 0.3 * loss1 + 1 * loss2 + 0.3 * loss3
         loss_gf.backward()
+        _rt.join_side()
         self.out.update(loss_gf=loss_gf.detach())
 
     def _update_B(self):
@@ -89,6 +92,7 @@ class DAStep:
             loss2 = to * c['rd'](y_t, y_t_adv, None, b['w_t'], mode='min')
             loss_gt = 0.3 * loss1 + 1 * loss2
             loss_gt.backward()
+            _rt.join_side()
         finally:
             if self.skip:
                 for p in self._adv_params:

@@ -12,6 +12,7 @@ import math
 import torch
 import torch.nn as nn
 
+import mi355 as _rt
 from . import Mi355Error, compute_dtype
 from . import ops
 
@@ -104,11 +105,11 @@ class _ConvFn(torch.autograd.Function):
         mod, desc = ctx.mod, ctx.desc
         dy = _as_grad(dy, x.dtype)
         dx = None
+        if ctx.needs_input_grad[1]:
+            mod._wgrad(desc, x, dy, weight)          # off the critical path: side stream
         if ctx.needs_input_grad[0]:
             _, _, wt = mod._plan(x)
             dx = ops.conv_dgrad(desc, dy, wt, scale_dev=ctx.scale_dev)
-        if ctx.needs_input_grad[1]:
-            mod._wgrad(desc, x, dy, weight)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             g, acc = grad_slot(bias)
             ops.colsum(dy, g, acc)
@@ -133,12 +134,16 @@ class _DeconvFn(torch.autograd.Function):
         mod, desc = ctx.mod, ctx.desc
         dy = _as_grad(dy, x.dtype)
         dx = None
+        if ctx.needs_input_grad[1]:
+            g, acc = grad_slot(weight)
+            if _rt.SIDE_WGRAD:
+                with _rt.on_side(x.device, keep=(x, dy)):
+                    ops.conv_wgrad(desc, dy, x, g, acc, ws_tag='side')      # conv-form input = dy, conv-form output = x
+            else:
+                ops.conv_wgrad(desc, dy, x, g, acc)
         if ctx.needs_input_grad[0]:
             _, wf, _ = mod._plan(x)
             dx = ops.conv_fwd(desc, dy, wf)
-        if ctx.needs_input_grad[1]:
-            g, acc = grad_slot(weight)
-            ops.conv_wgrad(desc, dy, x, g, acc)      # conv-form input = dy, conv-form output = x
         return dx, None, None
 
 
@@ -290,7 +295,11 @@ class Conv2d(nn.Module):
     def _wgrad(self, desc, x, dy, weight):
         g, acc = grad_slot(weight)
         if desc.Ci == self.in_channels:
-            ops.conv_wgrad(desc, x, dy, g, acc)
+            if _rt.SIDE_WGRAD:
+                with _rt.on_side(x.device, keep=(x, dy)):
+                    ops.conv_wgrad(desc, x, dy, g, acc, ws_tag='side')
+            else:
+                ops.conv_wgrad(desc, x, dy, g, acc)
         else:   # stem: kernel works on the padded channel count; un-pad into the (Co,3,7,7) gradient
             k = self.kernel_size[0]
             if self._stem_tmp is None or self._stem_tmp.device != x.device:

@@ -75,11 +75,11 @@ def conv_dgrad(desc, dy, wT, scale_dev=None, out=None, accumulate=False):
     return dx
 
 
-def conv_wgrad(desc, x, dy, dw, accumulate):
+def conv_wgrad(desc, x, dy, dw, accumulate, ws_tag='main'):
     """dw: fp32 buffer in [Co][kh][kw][Ci] memory order (Ci = desc.Ci, i.e. padded for the stem)."""
     _chk_dev(x, dy, dw)
     need = load().mi355_conv_wgrad_workspace(ctypes.byref(desc))
-    ws = workspace(need, x.device)
+    ws = workspace(need, x.device, ws_tag)
     call('mi355_conv_wgrad', ctypes.byref(desc), ptr(x), ptr(dy), ptr(dw), int(accumulate), ptr(ws), ws.numel(),
          stream_ptr())
 

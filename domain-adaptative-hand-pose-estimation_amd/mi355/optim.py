@@ -9,6 +9,7 @@ the reference checkpoint keys keep working.  Parameters that have never received
 import torch
 from torch.optim import Optimizer
 
+import mi355 as _rt
 from . import ops
 from .nn import mark_grads_fresh
 
@@ -69,6 +70,7 @@ class FusedSGD(Optimizer):
 
     def flat_grads(self):
         """The contiguous gradient buffers (one per group) — what the data-parallel all-reduce operates on."""
+        _rt.join_side()
         self.ensure_flat()
         return [f['G'] for f in self._flat if f is not None]
 
@@ -96,6 +98,7 @@ class FusedSGD(Optimizer):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
+        _rt.join_side()              # weight gradients computed on the side stream must have landed
         self.ensure_flat()
         if not torch.cuda.is_current_stream_capturing():
             self.sync_lr()
