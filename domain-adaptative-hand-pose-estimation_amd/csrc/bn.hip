@@ -154,6 +154,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, 
 template <typename T, bool XHAT>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict__ dy, const T* __restrict__ x, const T* __restrict__ y,
                                                              const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
                                                              float* __restrict__ partial, long rows, int C, int TX, int rows_per_slice, int relu) {
   constexpr int CH = Chunk<T>::N;
   __shared__ float sh[256 * CH * 2];
@@ -163,21 +164,28 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
   const bool colok = chunk * CH < C;
   const long r0 = (long)blockIdx.y * rows_per_slice;
   long r1 = r0 + rows_per_slice; if (r1 > rows) r1 = rows;
-  float s1[CH], s2[CH], mu[CH], is[CH];
+  float s1[CH], s2[CH], mu[CH], is[CH], sc[CH], sft[CH];
 #pragma unroll
-  for (int e = 0; e < CH; ++e) { s1[e] = 0.f; s2[e] = 0.f; mu[e] = 0.f; is[e] = 0.f; }
+  for (int e = 0; e < CH; ++e) { s1[e] = 0.f; s2[e] = 0.f; mu[e] = 0.f; is[e] = 0.f; sc[e] = 0.f; sft[e] = 0.f; }
   if (colok && XHAT) {
 #pragma unroll
     for (int e = 0; e < CH; ++e) { mu[e] = mean[chunk * CH + e]; is[e] = invstd[chunk * CH + e]; }
+    if (relu == 2) {   // forward's exact scale/shift (bn_finalize_kernel): the ReLU mask is recomputed from x, y is not read
+#pragma unroll
+      for (int e = 0; e < CH; ++e) { sc[e] = gamma[chunk * CH + e] * is[e]; sft[e] = beta[chunk * CH + e] - mu[e] * sc[e]; }
+    }
   }
   if (colok)
     for (long r = r0 + ty; r < r1; r += TY) {
       const size_t off = (size_t)r * C + (size_t)chunk * CH;
       float g[CH]; Chunk<T>::load(dy + off, g);
-      if (relu) { float o[CH]; Chunk<T>::load(y + off, o);
+      if (relu == 1) { float o[CH]; Chunk<T>::load(y + off, o);
 #pragma unroll
         for (int e = 0; e < CH; ++e) g[e] = o[e] > 0.f ? g[e] : 0.f; }
       if (XHAT) { float v[CH]; Chunk<T>::load(x + off, v);
+        if (relu == 2) {
+#pragma unroll
+          for (int e = 0; e < CH; ++e) g[e] = (v[e] * sc[e] + sft[e]) > 0.f ? g[e] : 0.f; }
 #pragma unroll
         for (int e = 0; e < CH; ++e) { s1[e] += g[e]; s2[e] += g[e] * ((v[e] - mu[e]) * is[e]); }
       } else {
@@ -228,25 +236,30 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
 template <typename T>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ dy, const T* __restrict__ x, const T* __restrict__ y,
                                                             const float* __restrict__ mean, const float* __restrict__ invstd,
-                                                            const float* __restrict__ coeff, T* __restrict__ dx, T* __restrict__ dres,
+                                                            const float* __restrict__ coeff, const float* __restrict__ beta,
+                                                            T* __restrict__ dx, T* __restrict__ dres,
                                                             long rows, int C, int TX, int relu) {
   constexpr int CH = Chunk<T>::N;
   const int TY = 256 / TX;
   const int tx = threadIdx.x % TX, ty = threadIdx.x / TX;
   const int chunk = blockIdx.x * TX + tx;
   if (chunk * CH >= C) return;
-  float k0[CH], k1[CH], k2[CH], mu[CH], is[CH];
+  float k0[CH], k1[CH], k2[CH], mu[CH], is[CH], sh[CH];
 #pragma unroll
   for (int e = 0; e < CH; ++e) {
     const int c = chunk * CH + e;
     k0[e] = coeff[c]; k1[e] = coeff[C + c]; k2[e] = coeff[2 * C + c]; mu[e] = mean[c]; is[e] = invstd[c];
+    sh[e] = (relu == 2) ? beta[c] - mu[e] * k0[e] : 0.f;      // k0 = gamma*invstd = forward scale
   }
   for (long r = (long)blockIdx.y * TY + ty; r < rows; r += (long)gridDim.y * TY) {
     const size_t off = (size_t)r * C + (size_t)chunk * CH;
     float g[CH], v[CH]; Chunk<T>::load(dy + off, g); Chunk<T>::load(x + off, v);
-    if (relu) { float o[CH]; Chunk<T>::load(y + off, o);
+    if (relu == 1) { float o[CH]; Chunk<T>::load(y + off, o);
 #pragma unroll
       for (int e = 0; e < CH; ++e) g[e] = o[e] > 0.f ? g[e] : 0.f; }
+    else if (relu == 2) {
+#pragma unroll
+      for (int e = 0; e < CH; ++e) g[e] = (v[e] * k0[e] + sh[e]) > 0.f ? g[e] : 0.f; }
     if (dres) Chunk<T>::store(dres + off, g);
 #pragma unroll
     for (int e = 0; e < CH; ++e) v[e] = k0[e] * (g[e] - k1[e] - (v[e] - mu[e]) * is[e] * k2[e]);
@@ -319,23 +332,26 @@ extern "C" int mi355_bn_eval_fwd(const void* x, const void* residual, void* y, c
   return MI355_OK;
 }
 
-extern "C" int mi355_bn_bwd(const void* dy, const void* x, const void* y, const float* gamma, const float* save_mean,
+extern "C" int mi355_bn_bwd(const void* dy, const void* x, const void* y, const float* gamma, const float* beta, const float* save_mean,
                             const float* save_invstd, void* dx, void* dresidual, float* dgamma, float* dbeta, int accumulate,
                             long rows, int C, int relu, int dtype, void* ws, size_t ws_bytes, void* stream) {
   int CH; if (int e = bn_check(rows, C, dtype, &CH)) return e;
   if (!ws || ws_bytes < mi355_bn_workspace(rows, C)) MI_FAIL(MI355_EWORKSPACE, "bn_bwd: workspace too small");
-  if (relu && !y) MI_FAIL(MI355_EINVAL, "bn_bwd: relu needs y");
+  // relu: the mask comes from y when it is given; without y it is recomputed from x (only valid when the forward had
+  // no residual add), which saves one tensor read in each of the two passes
+  if (relu) relu = y ? 1 : 2;
+  if (relu == 2 && !beta) MI_FAIL(MI355_EINVAL, "bn_bwd: relu without y needs beta");
   hipStream_t st = as_stream(stream);
   BnPlan p = bn_plan(rows, C, CH);
   float* partial = reinterpret_cast<float*>(ws);
   float* coeff = partial + (size_t)p.nslices * C * 3;   // 3*C floats (4*C reserved)
   dim3 g(p.colgroups, p.nslices);
-  if (dtype == MI355_BF16) hipLaunchKernelGGL((bn_bwd_reduce_kernel<bf16_t, true>), g, dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)x, (const bf16_t*)y, save_mean, save_invstd, partial, rows, C, p.TX, p.rows_per_slice, relu);
-  else hipLaunchKernelGGL((bn_bwd_reduce_kernel<float, true>), g, dim3(256), 0, st, (const float*)dy, (const float*)x, (const float*)y, save_mean, save_invstd, partial, rows, C, p.TX, p.rows_per_slice, relu);
+  if (dtype == MI355_BF16) hipLaunchKernelGGL((bn_bwd_reduce_kernel<bf16_t, true>), g, dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)x, (const bf16_t*)y, save_mean, save_invstd, gamma, beta, partial, rows, C, p.TX, p.rows_per_slice, relu);
+  else hipLaunchKernelGGL((bn_bwd_reduce_kernel<float, true>), g, dim3(256), 0, st, (const float*)dy, (const float*)x, (const float*)y, save_mean, save_invstd, gamma, beta, partial, rows, C, p.TX, p.rows_per_slice, relu);
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 4)), dim3(256), 0, st, partial, p.nslices, C, 1.0f / (float)rows, gamma, save_invstd, dgamma, dbeta, accumulate, coeff);
   dim3 ga = apply_grid(p, rows);
-  if (dtype == MI355_BF16) hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, ga, dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)x, (const bf16_t*)y, save_mean, save_invstd, coeff, (bf16_t*)dx, (bf16_t*)dresidual, rows, C, p.TX, relu);
-  else hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, ga, dim3(256), 0, st, (const float*)dy, (const float*)x, (const float*)y, save_mean, save_invstd, coeff, (float*)dx, (float*)dresidual, rows, C, p.TX, relu);
+  if (dtype == MI355_BF16) hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, ga, dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)x, (const bf16_t*)y, save_mean, save_invstd, coeff, beta, (bf16_t*)dx, (bf16_t*)dresidual, rows, C, p.TX, relu);
+  else hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, ga, dim3(256), 0, st, (const float*)dy, (const float*)x, (const float*)y, save_mean, save_invstd, coeff, beta, (float*)dx, (float*)dresidual, rows, C, p.TX, relu);
   MI_CHECK_LAUNCH("bn_bwd");
   return MI355_OK;
 }
@@ -348,8 +364,8 @@ extern "C" int mi355_colsum(const void* dy, float* out, long rows, int C, int dt
   BnPlan p = bn_plan(rows, C, CH);
   float* partial = reinterpret_cast<float*>(ws);
   dim3 g(p.colgroups, p.nslices);
-  if (dtype == MI355_BF16) hipLaunchKernelGGL((bn_bwd_reduce_kernel<bf16_t, false>), g, dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)nullptr, (const bf16_t*)nullptr, (const float*)nullptr, (const float*)nullptr, partial, rows, C, p.TX, p.rows_per_slice, 0);
-  else hipLaunchKernelGGL((bn_bwd_reduce_kernel<float, false>), g, dim3(256), 0, st, (const float*)dy, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, partial, rows, C, p.TX, p.rows_per_slice, 0);
+  if (dtype == MI355_BF16) hipLaunchKernelGGL((bn_bwd_reduce_kernel<bf16_t, false>), g, dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)nullptr, (const bf16_t*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, partial, rows, C, p.TX, p.rows_per_slice, 0);
+  else hipLaunchKernelGGL((bn_bwd_reduce_kernel<float, false>), g, dim3(256), 0, st, (const float*)dy, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, partial, rows, C, p.TX, p.rows_per_slice, 0);
   hipLaunchKernelGGL(colsum_finalize_kernel, dim3(cdiv(C, 4)), dim3(256), 0, st, partial, p.nslices, C, out, accumulate);
   MI_CHECK_LAUNCH("colsum");
   return MI355_OK;

@@ -42,7 +42,7 @@ SIGNATURES = {
     'mi355_bn_workspace': (_Z, [_L, _I]),
     'mi355_bn_train_fwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _F, _F, _I, _I, _P, _Z, _P]),
     'mi355_bn_eval_fwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _L, _I, _F, _I, _I, _P]),
-    'mi355_bn_bwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _L, _I, _I, _I, _P, _Z, _P]),
+    'mi355_bn_bwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _L, _I, _I, _I, _P, _Z, _P]),
     'mi355_maxpool_fwd': (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
     'mi355_maxpool_bwd': (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
     'mi355_nchw_to_nhwc': (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),

@@ -89,6 +89,9 @@ def _chk_convform(weight):
 
 
 # ---------------------------------------------------------------- autograd functions
+import os as _os
+_MASK_FROM_Y = _os.environ.get('MI355_BN_MASK_FROM_Y', '0') == '1'     # A/B switch: read y for every ReLU mask
+
 class _ConvFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, residual, mod, scale_dev):
@@ -153,7 +156,9 @@ class _BnFn(torch.autograd.Function):
         y, mean, invstd = ops.bn_train_fwd(x, residual, gamma, beta, mod.running_mean, mod.running_var,
                                            mod.num_batches_tracked, mod.eps, mod.momentum, relu)
         ctx.relu = relu
-        ctx.save_for_backward(x, y if relu else None, mean, invstd, gamma, beta)
+        # the ReLU mask is recomputed from x in backward unless a residual was added (then it needs y)
+        keep_y = relu and (residual is not None or _MASK_FROM_Y)
+        ctx.save_for_backward(x, y if keep_y else None, mean, invstd, gamma, beta)
         return y
 
     @staticmethod
@@ -167,7 +172,7 @@ class _BnFn(torch.autograd.Function):
         if ctx.needs_input_grad[2]:
             db, acc_b = grad_slot(beta)
             acc = acc_b if dg is None else acc
-        dx, dres = ops.bn_bwd(dy, x, y, gamma, mean, invstd, dg, db, acc, ctx.relu, ctx.needs_input_grad[3])
+        dx, dres = ops.bn_bwd(dy, x, y, gamma, mean, invstd, dg, db, acc, ctx.relu, ctx.needs_input_grad[3], beta=beta)
         return (dx if ctx.needs_input_grad[0] else None), None, None, dres, None, None
 
 

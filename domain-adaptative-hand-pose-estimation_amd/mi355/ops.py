@@ -131,13 +131,13 @@ def bn_eval_fwd(x, residual, gamma, beta, running_mean, running_var, eps, relu):
     return y
 
 
-def bn_bwd(dy, x, y, gamma, mean, invstd, dgamma, dbeta, accumulate, relu, want_dres):
+def bn_bwd(dy, x, y, gamma, mean, invstd, dgamma, dbeta, accumulate, relu, want_dres, beta=None):
     N, C, H, W = x.shape
     rows = N * H * W
     dx = nhwc_empty(N, C, H, W, x.dtype, x.device)
     dres = nhwc_empty(N, C, H, W, x.dtype, x.device) if want_dres else None
     ws = workspace(load().mi355_bn_workspace(rows, C), x.device)
-    call('mi355_bn_bwd', ptr(dy), ptr(x), ptr(y), ptr(gamma), ptr(mean), ptr(invstd), ptr(dx), ptr(dres),
+    call('mi355_bn_bwd', ptr(dy), ptr(x), ptr(y), ptr(gamma), ptr(beta), ptr(mean), ptr(invstd), ptr(dx), ptr(dres),
          ptr(dgamma), ptr(dbeta), int(accumulate), rows, C, int(relu), dtype_code(x.dtype), ptr(ws), ws.numel(),
          stream_ptr())
     return dx, dres

@@ -89,6 +89,8 @@ int mi355_colsum(const void* dy, float* out, long rows, int C, int dtype, int ac
  * save_mean / save_invstd: fp32 [C] outputs consumed by mi355_bn_bwd.
  * bwd: dy_eff = relu ? dy*(y>0) : dy ; dx = gamma*invstd*(dy_eff - mean(dy_eff) - xhat*mean(dy_eff*xhat));
  *      dresidual (nullable) = dy_eff ; dgamma/dbeta (=|+=).
+ *      With relu and y == NULL the mask is recomputed from x (valid when the forward had no residual): one
+ *      tensor read less in each backward pass.
  */
 size_t mi355_bn_workspace(long rows, int C);
 int mi355_bn_train_fwd(const void* x, const void* residual, void* y, const float* gamma, const float* beta,
@@ -98,8 +100,8 @@ int mi355_bn_train_fwd(const void* x, const void* residual, void* y, const float
 int mi355_bn_eval_fwd(const void* x, const void* residual, void* y, const float* gamma, const float* beta,
                       const float* running_mean, const float* running_var, long rows, int C, float eps,
                       int relu, int dtype, void* stream);
-int mi355_bn_bwd(const void* dy, const void* x, const void* y, const float* gamma, const float* save_mean,
-                 const float* save_invstd, void* dx, void* dresidual, float* dgamma, float* dbeta,
+int mi355_bn_bwd(const void* dy, const void* x, const void* y, const float* gamma, const float* beta,
+                 const float* save_mean, const float* save_invstd, void* dx, void* dresidual, float* dgamma, float* dbeta,
                  int accumulate, long rows, int C, int relu, int dtype, void* ws, size_t ws_bytes,
                  void* stream);
 

@@ -143,7 +143,9 @@ def test_bn_train_fwd_bwd(gpu, dt, shape, relu, res):
     assert int(nbt) == 1
     dg = torch.zeros(C, device=gpu); db = torch.zeros(C, device=gpu)
     # backward consumes the library's own y (bf16-rounded) for the ReLU mask
-    dx, dres = ops.bn_bwd(_nhwc(dy, dt, gpu), xd, y if relu else None, gamma.to(gpu), mean, invstd, dg, db, False, relu, res)
+    # with a residual the ReLU mask needs the forward output y; without it the mask is recomputed from x (y=None)
+    dx, dres = ops.bn_bwd(_nhwc(dy, dt, gpu), xd, y if (relu and res) else None, gamma.to(gpu), mean, invstd, dg, db, False, relu, res,
+                          beta=beta.to(gpu))
     gtol = _tol(dt, xr.grad) * (3 if dt == 'bf16' else 1)
     assert float((_back(dx) - xr.grad).abs().max()) <= gtol
     if res:
