@@ -23,6 +23,7 @@ struct GatherArgs {
   int M;
   int accumulate;
   int ntm, ntn;
+  int hw;                      // heat-map output mode: pixels per image
   unsigned a_bytes, b_bytes;
   Tap taps[MAX_TAPS];
 };
@@ -63,7 +64,8 @@ struct GatherSmem {
 };
 
 // WGM x WGN waves per workgroup (64 lanes each); every wave owns a (BM/WGM) x (BN/WGN) sub-tile.
-template <typename T, int BM, int BN, bool SMALL_C, int WGM = 2, int WGN = 2>
+// HM_OUT: the result is written as NCHW fp32 heat-maps [image][Nout][hw] (the 1x1 conv to the K=21 key-point maps).
+template <typename T, int BM, int BN, bool SMALL_C, int WGM = 2, int WGN = 2, bool HM_OUT = false>
 __global__ __launch_bounds__(64 * WGM * WGN) void gather_gemm_kernel(const GatherArgs p) {
   constexpr int CH = MmaTraits<T>::CH;
   constexpr int NTHR = 64 * WGM * WGN, RPP = NTHR / 8;      // rows staged per pass (8 lanes = one 128-byte row)
@@ -186,9 +188,36 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gather_gemm_kernel(const Gathe
   }
   __syncthreads();
 
+  char* outs = smem;
+  if constexpr (HM_OUT) {
+    // ---- heat-map epilogue: acc + bias -> fp32 LDS tile -> per key-point runs of BM consecutive pixels (512-byte rows)
+    constexpr int HS = BN * 4 + 16;
+    static_assert(BM * HS <= SM::kBytes - BM * 4, "fp32 staging tile must fit");
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int ml = wm0 + i * 32 + r31, nl = wn0 + j * 32 + 8 * g + 4 * hi;
+          float v[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * g + e] + ((p.bias && (nl + e) < p.Nout) ? p.bias[nl + e] : 0.f);
+          *reinterpret_cast<float4*>(outs + ml * HS + nl * 4) = make_float4(v[0], v[1], v[2], v[3]);
+        }
+    __syncthreads();
+    float* __restrict__ Y = reinterpret_cast<float*>(p.D);
+    for (int id = t; id < p.Nout * BM; id += NTHR) {
+      const int k = id / BM, r = id % BM;
+      const int gp = row_off[r];                       // global pixel index (ldd == 1)
+      if (gp < 0) continue;
+      const int img = gp / p.hw, pp = gp - img * p.hw;
+      Y[((size_t)img * p.Nout + k) * p.hw + pp] = *reinterpret_cast<const float*>(outs + r * HS + k * 4);
+    }
+    return;
+  }
   // ---- epilogue: (acc + bias) * scale -> T -> LDS tile -> coalesced 16-byte rows (+residual / +dx)
   const float scale = p.scale ? *p.scale : 1.0f;
-  char* outs = smem;
 #pragma unroll
   for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -402,11 +431,11 @@ __global__ void zero_fill_kernel(uint4* __restrict__ p, size_t n16) {
 // ------------------------------------------------------------------------------------ host side
 static int ilog2_exact(int v) { int s = 0; while ((1 << s) < v) ++s; return ((1 << s) == v) ? s : -1; }
 
-template <typename T, int BM, int BN, bool SMALL_C, int WGM = 2, int WGN = 2>
+template <typename T, int BM, int BN, bool SMALL_C, int WGM = 2, int WGN = 2, bool HM_OUT = false>
 static void launch_gather(GatherArgs& a, hipStream_t st) {
   a.ntm = cdiv(a.M, BM); a.ntn = cdiv(a.Nout, BN);
   constexpr int smem = GatherSmem<T, BM, BN>::kBytes;
-  auto kern = gather_gemm_kernel<T, BM, BN, SMALL_C, WGM, WGN>;
+  auto kern = gather_gemm_kernel<T, BM, BN, SMALL_C, WGM, WGN, HM_OUT>;
   static bool attr_set = false;   // raise the dynamic-LDS cap once per instantiation
   if (!attr_set) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem); attr_set = true; }
   hipLaunchKernelGGL(kern, dim3(a.ntm * a.ntn), dim3(64 * WGM * WGN), smem, st, a);
@@ -466,6 +495,35 @@ extern "C" int mi355_conv_fwd(const mi355_conv_desc* d, const void* x, const voi
   for (int i = 0; i < d->kh; ++i)
     for (int j = 0; j < d->kw; ++j) { Tap& t = a.taps[i * d->kw + j]; t.dy = (int8_t)(i - d->pad); t.dx = (int8_t)(j - d->pad); t.widx = (int16_t)(i * d->kw + j); }
   return d->dtype == MI355_BF16 ? dispatch_gather<bf16_t>(a, as_stream(stream)) : dispatch_gather<float>(a, as_stream(stream));
+}
+
+// 1x1 conv C -> K (K <= 32) written as NCHW fp32 heat-maps: y[n][k][p] = bias[k] + sum_c x[n*HW+p][c] * w[k][c]
+template <typename T>
+static int heatmap_conv(const void* x, const void* w, const float* bias, float* y, int N, int HW, int C, int K, hipStream_t st) {
+  constexpr int CH = MmaTraits<T>::CH;
+  GatherArgs a; memset(&a, 0, sizeof(a));
+  a.A = x; a.B = w; a.D = y; a.bias = bias;
+  a.Hi = 1; a.Wi = HW; a.Ci = C; a.OHp = 1; a.OWp = HW; a.in_sy = a.in_sx = 1;
+  a.Ho = 1; a.Wo = HW; a.out_sy = a.out_sx = 1; a.ldd = 1; a.hw = HW;
+  a.Nout = K; a.ldb = C; a.M = N * HW; a.ntaps = 1;
+  if (C % CH) MI_FAIL(MI355_EINVAL, "conv1x1_heatmap: C=%d not a multiple of %d", C, CH);
+  a.cshift = ilog2_exact(C / CH);
+  if (a.cshift < 3) MI_FAIL(MI355_EINVAL, "conv1x1_heatmap: C/%d must be a power of two >= 8 (C=%d)", CH, C);
+  a.kchunks = 1 << a.cshift;
+  a.a_bytes = (unsigned)((long)N * HW * C * (long)sizeof(T));
+  a.b_bytes = (unsigned)((long)K * C * (long)sizeof(T));
+  ProfScope ps(st, 2.0 * a.M * (double)K * C);
+  launch_gather<T, 128, 32, false, 4, 1, true>(a, st);
+  MI_CHECK_LAUNCH("conv1x1_heatmap");
+  return MI355_OK;
+}
+extern "C" int mi355_conv1x1_heatmap(const void* x, const void* w, const float* bias, float* y, int N, int HW, int C, int K,
+                                     int dtype, void* stream) {
+  if (!x || !w || !y || N < 1 || HW < 1 || K < 1 || K > 32) MI_FAIL(MI355_EINVAL, "conv1x1_heatmap: bad args");
+  if ((long)N * HW * C >= (1L << 31)) MI_FAIL(MI355_EINVAL, "conv1x1_heatmap: tensor too large");
+  return dtype == MI355_BF16 ? heatmap_conv<bf16_t>(x, w, bias, y, N, HW, C, K, as_stream(stream))
+       : dtype == MI355_F32 ? heatmap_conv<float>(x, w, bias, y, N, HW, C, K, as_stream(stream))
+       : (mi355_set_error("bad dtype"), MI355_EINVAL);
 }
 
 // conv-form dgrad: dx[n][iy][ix][ci] = sum_{kh,kw,co} dy[n][(iy+p-kh)/s][(ix+p-kw)/s][co] * w[co][kh][kw][ci]

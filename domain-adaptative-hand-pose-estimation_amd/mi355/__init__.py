@@ -47,6 +47,7 @@ SIGNATURES = {
     'mi355_maxpool_bwd': (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
     'mi355_nchw_to_nhwc': (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
     'mi355_nhwc_to_nchw': (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
+    'mi355_conv1x1_heatmap': (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     'mi355_pw_c2k': (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     'mi355_pw_k2c': (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     'mi355_pw_wgrad_workspace': (_Z, [_I, _I, _I, _I]),

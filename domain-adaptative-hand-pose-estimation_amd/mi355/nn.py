@@ -190,13 +190,54 @@ class _MaxPoolFn(torch.autograd.Function):
         return ops.maxpool_bwd(dy.contiguous(memory_format=torch.channels_last), arg, ctx.in_shape)
 
 
+_PW_MFMA = _os.environ.get('MI355_PW_MFMA', '1') != '0'      # A/B switch: MFMA forms of the heat-map convs
+
+
+class _CastCopy:
+    """compute-dtype copy of a small fp32 master ([K][C] / [C][K] point-wise weights), refreshed on change."""
+
+    def __init__(self):
+        self.key, self.buf = None, None
+
+    def get(self, w, dtype):
+        if dtype == torch.float32:
+            return w.detach()
+        key = (_param_version(w), dtype)
+        if key != self.key:
+            if self.buf is None or self.buf.device != w.device:
+                self.buf = torch.empty(w.numel(), dtype=dtype, device=w.device)
+            ops.cast_f32(w.detach(), self.buf)
+            self.key = key
+        return self.buf
+
+
+def _pw_wgrad_mfma(feat, hm, g, acc, kc_layout):
+    """Weight gradient of a 1x1 conv between NHWC features `feat` [N,C,H,W] and heat-maps `hm` [N,K,H,W] on the
+    MFMA wgrad kernel: the heat-map operand is re-laid as NHWC with K padded to 32 channels (16 MB at B=64)."""
+    N, C, H, W = feat.shape
+    K = hm.shape[1]
+    hm32 = ops.to_nhwc(hm, feat.dtype, 32)
+    tmp = torch.empty(32 * C, dtype=torch.float32, device=feat.device)
+    if kc_layout:      # dW[k][c] = sum_p hm[p][k] * feat[p][c]  : conv-form x=feat (Ci=C), dy=hm32 (Co=32)
+        ops.conv_wgrad(ops.make_desc(N, H, W, C, 32, 1, 1, 1, 0, feat.dtype), feat, hm32, tmp, False)
+        src = tmp.view(32, C)[:K]
+    else:              # dW[c][k] = sum_p feat[p][c] * hm[p][k] : conv-form x=hm32 (Ci=32), dy=feat (Co=C)
+        ops.conv_wgrad(ops.make_desc(N, H, W, 32, C, 1, 1, 1, 0, feat.dtype), hm32, feat, tmp, False)
+        src = tmp.view(C, 32)[:, :K]
+    dst = g.view(src.shape)
+    dst.add_(src) if acc else dst.copy_(src)
+
+
 class _PwC2KFn(torch.autograd.Function):
     """1x1 conv C -> K heat-map (NHWC features in, NCHW fp32 heat-map out)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, scale_dev):
+    def forward(ctx, x, weight, bias, scale_dev, mod):
         K = weight.shape[0]
-        y = ops.pw_c2k(x, weight.detach(), bias, K)
+        if _PW_MFMA:
+            y = ops.conv1x1_heatmap(x, mod._cast.get(weight, x.dtype), bias, K)
+        else:
+            y = ops.pw_c2k(x, weight.detach(), bias, K)
         ctx.scale_dev = scale_dev
         ctx.has_bias = bias is not None
         ctx.save_for_backward(x, weight, bias)
@@ -211,11 +252,14 @@ class _PwC2KFn(torch.autograd.Function):
             dx = ops.pw_k2c(dy, weight.detach(), None, x.shape[1], x.dtype, scale_dev=ctx.scale_dev, w_transposed=True)
         if ctx.needs_input_grad[1]:
             g, acc = grad_slot(weight)
-            ops.pw_wgrad(x, dy, g, True, acc)
+            if _PW_MFMA:
+                _pw_wgrad_mfma(x, dy, g, acc, True)
+            else:
+                ops.pw_wgrad(x, dy, g, True, acc)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             g, acc = grad_slot(bias)
             ops.hm_rowsum(dy, g, acc)
-        return dx, None, None, None
+        return dx, None, None, None, None
 
 
 class _PwK2CFn(torch.autograd.Function):
@@ -238,7 +282,10 @@ class _PwK2CFn(torch.autograd.Function):
             dhm = ops.pw_c2k(dout, weight.detach(), None, hm.shape[1], w_transposed=True)
         if ctx.needs_input_grad[1]:
             g, acc = grad_slot(weight)
-            ops.pw_wgrad(dout, hm, g, False, acc)
+            if _PW_MFMA:
+                _pw_wgrad_mfma(dout, hm, g, acc, False)
+            else:
+                ops.pw_wgrad(dout, hm, g, False, acc)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             g, acc = grad_slot(bias)
             ops.colsum(dout, g, acc)
@@ -260,6 +307,7 @@ class Conv2d(nn.Module):
         self.weight = _convform_param(out_channels, in_channels, k, k)
         self.bias = nn.Parameter(torch.empty(out_channels)) if bias else None
         self._packed = _PackedWeights()
+        self._cast = _CastCopy()
         self._stem_tmp = None
         self.reset_parameters()
 
@@ -320,7 +368,7 @@ class Conv2d(nn.Module):
         scale = getattr(x, '_mi_grad_scale', None)
         if mode == 'c2k':
             x = _as_feature(x, dtype)
-            return _PwC2KFn.apply(x, self.weight, self.bias, scale)
+            return _PwC2KFn.apply(x, self.weight, self.bias, scale, self)
         if mode == 'k2c':
             if x.dtype != torch.float32 or not x.is_contiguous():
                 x = x.float().contiguous()

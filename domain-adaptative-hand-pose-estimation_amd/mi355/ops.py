@@ -161,6 +161,14 @@ def maxpool_bwd(dy, arg, in_shape):
 
 
 # ---------------------------------------------------------------- 21-channel pointwise convs
+def conv1x1_heatmap(x, w_packed, bias, K):
+    """MFMA form of the C -> K heat-map conv: x channels_last [N,C,H,W], w_packed [K][C] in x.dtype -> [N,K,H,W] fp32."""
+    N, C, H, W = x.shape
+    y = torch.empty((N, K, H, W), dtype=torch.float32, device=x.device)
+    call('mi355_conv1x1_heatmap', ptr(x), ptr(w_packed), ptr(bias), ptr(y), N, H * W, C, K, dtype_code(x.dtype), stream_ptr())
+    return y
+
+
 def pw_c2k(x, w, bias, K, w_transposed=False):
     """x channels_last [N,C,H,W] -> heat-map [N,K,H,W] fp32 contiguous."""
     N, C, H, W = x.shape

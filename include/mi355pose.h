@@ -129,6 +129,9 @@ int mi355_nhwc_to_nchw(const void* x, float* y, int N, int C, int H, int W, int 
  *  w_transposed!=0: w is stored the other way round ([C][K] for c2k, [K][C] for k2c), which is how the
  *  input-gradient of each op reuses the other op with the same weight tensor.
  */
+/* MFMA form of c2k (forward of the heads' last conv): w is the packed `dtype` copy [K][C]; K <= 32, C/chunk a power of 2. */
+int mi355_conv1x1_heatmap(const void* x, const void* w, const float* bias, float* y, int N, int HW, int C, int K,
+                          int dtype, void* stream);
 int mi355_pw_c2k(const void* x, const float* w, const float* bias, float* y, int N, int HW, int C, int K,
                  int w_transposed, int dtype, void* stream);
 int mi355_pw_k2c(const float* y, const float* w, const float* bias, const void* residual,

@@ -220,6 +220,22 @@ def test_pointwise21(gpu, dt):
     assert torch.allclose(rs.cpu(), hm.sum(dim=(0, 2, 3)), rtol=1e-4, atol=1e-3)
 
 
+@pytest.mark.parametrize('dt', ['f32', 'bf16'])
+@pytest.mark.parametrize('hw', [(64, 64), (16, 16), (10, 12)])
+def test_conv1x1_heatmap_mfma(gpu, dt, hw):
+    """MFMA form of the C -> 21 heat-map conv (NCHW fp32 epilogue), incl. a map whose size is not a tile multiple."""
+    ops = _ops()
+    N, C, K = 3, 256, 21
+    H, W = hw
+    x = _round(randn(48, N, C, H, W), dt)
+    w = _round(randn(49, K, C, scale=0.06), dt)
+    b = randn(50, K, scale=0.1)
+    y = ops.conv1x1_heatmap(_nhwc(x, dt, gpu), w.to(gpu).to(DT[dt]).contiguous(), b.to(gpu), K)
+    ref = F.conv2d(x, w.view(K, C, 1, 1), b)
+    assert y.dtype == torch.float32 and y.is_contiguous()
+    assert float((y.cpu() - ref).abs().max()) <= 1e-3 * float(ref.abs().max())
+
+
 def test_argmax_bit_exact_and_accuracy(gpu):
     """Golden G4 (captured from the reference's numpy get_max_preds): integer indices bit-exact."""
     ops = _ops()
