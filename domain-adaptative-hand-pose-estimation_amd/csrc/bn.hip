@@ -87,10 +87,10 @@ __device__ __forceinline__ void chan_combine(float& n, float& mean, float& m2, f
 __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ partial, int nslices, int C, const float* __restrict__ gamma,
                                    const float* __restrict__ beta, float* running_mean, float* running_var,
                                    int64_t* nbt, float* save_mean, float* save_invstd, float* scale_shift, float eps,
-                                   float momentum) {
+                                   float momentum, int repeats) {
   const int lane = threadIdx.x & 63;
   const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (blockIdx.x == 0 && threadIdx.x == 0 && nbt) *nbt += 1;
+  if (blockIdx.x == 0 && threadIdx.x == 0 && nbt) *nbt += repeats;
   if (c >= C) return;                      // wave-uniform
   float qn[16], qm[16], qv[16];
 #pragma unroll
@@ -111,8 +111,12 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
   const float var = m2 / n;
   const float invstd = 1.0f / sqrtf(var + eps);
   save_mean[c] = mean; save_invstd[c] = invstd;
-  if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
-  if (running_var) running_var[c] = (1.f - momentum) * running_var[c] + momentum * (n > 1.f ? m2 / (n - 1.f) : var);
+  // `repeats` identical forward passes over the same batch (training step B -> C reuse) = that many momentum updates
+  const float uvar = n > 1.f ? m2 / (n - 1.f) : var;
+  for (int r = 0; r < repeats; ++r) {
+    if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
+    if (running_var) running_var[c] = (1.f - momentum) * running_var[c] + momentum * uvar;
+  }
   const float sc = gamma[c] * invstd;
   scale_shift[c] = sc; scale_shift[C + c] = beta[c] - mean * sc;
 }
@@ -298,9 +302,10 @@ static dim3 apply_grid(const BnPlan& p, long rows) {
 
 extern "C" int mi355_bn_train_fwd(const void* x, const void* residual, void* y, const float* gamma, const float* beta,
                                   float* running_mean, float* running_var, int64_t* nbt, float* save_mean, float* save_invstd,
-                                  long rows, int C, float eps, float momentum, int relu, int dtype, void* ws, size_t ws_bytes,
-                                  void* stream) {
+                                  long rows, int C, float eps, float momentum, int stat_updates, int relu, int dtype, void* ws,
+                                  size_t ws_bytes, void* stream) {
   int CH; if (int e = bn_check(rows, C, dtype, &CH)) return e;
+  if (stat_updates < 0 || stat_updates > 8) MI_FAIL(MI355_EINVAL, "bn_train_fwd: stat_updates=%d", stat_updates);
   if (!ws || ws_bytes < mi355_bn_workspace(rows, C)) MI_FAIL(MI355_EWORKSPACE, "bn_train_fwd: workspace too small");
   hipStream_t st = as_stream(stream);
   BnPlan p = bn_plan(rows, C, CH);
@@ -309,7 +314,7 @@ extern "C" int mi355_bn_train_fwd(const void* x, const void* residual, void* y, 
   dim3 g(p.colgroups, p.nslices);
   if (dtype == MI355_BF16) hipLaunchKernelGGL(bn_stats_kernel<bf16_t>, g, dim3(256), 0, st, (const bf16_t*)x, partial, rows, C, p.TX, p.rows_per_slice);
   else hipLaunchKernelGGL(bn_stats_kernel<float>, g, dim3(256), 0, st, (const float*)x, partial, rows, C, p.TX, p.rows_per_slice);
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 4)), dim3(256), 0, st, partial, p.nslices, C, gamma, beta, running_mean, running_var, nbt, save_mean, save_invstd, ss, eps, momentum);
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 4)), dim3(256), 0, st, partial, p.nslices, C, gamma, beta, running_mean, running_var, nbt, save_mean, save_invstd, ss, eps, momentum, stat_updates);
   dim3 ga = apply_grid(p, rows);
   const float* nf = nullptr;
   if (dtype == MI355_BF16) hipLaunchKernelGGL((bn_apply_kernel<bf16_t, false>), ga, dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)residual, (bf16_t*)y, (const float*)ss, nf, nf, nf, nf, eps, rows, C, p.TX, relu);

@@ -40,7 +40,7 @@ SIGNATURES = {
     'mi355_colsum_workspace': (_Z, [_L, _I]),
     'mi355_colsum': (_I, [_P, _P, _L, _I, _I, _I, _P, _Z, _P]),
     'mi355_bn_workspace': (_Z, [_L, _I]),
-    'mi355_bn_train_fwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _F, _F, _I, _I, _P, _Z, _P]),
+    'mi355_bn_train_fwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _F, _F, _I, _I, _I, _P, _Z, _P]),
     'mi355_bn_eval_fwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _L, _I, _F, _I, _I, _P]),
     'mi355_bn_bwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _L, _I, _I, _I, _P, _Z, _P]),
     'mi355_maxpool_fwd': (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
@@ -130,6 +130,26 @@ def dtype_code(dt):
     if dt == torch.float32:
         return F32
     raise Mi355Error('unsupported dtype %s' % dt)
+
+
+# ---------------------------------------------------------------- BatchNorm running-stat update multiplicity
+bn_stat_updates = 1
+
+
+class bn_updates:
+    """with bn_updates(2): forwards inside apply the running-stat momentum update twice (one forward standing for two
+    identical forwards of the reference loop)."""
+
+    def __init__(self, n):
+        self.n = n
+
+    def __enter__(self):
+        global bn_stat_updates
+        self.prev, bn_stat_updates = bn_stat_updates, self.n
+
+    def __exit__(self, *exc):
+        global bn_stat_updates
+        bn_stat_updates = self.prev
 
 
 # ---------------------------------------------------------------- shared scratch (stream-ordered reuse)

@@ -6,6 +6,10 @@ Differences from the reference loop that do not change any result (documented in
     zeroed by ``optimizer_f.zero_grad()`` at the start of step C before anyone reads them (train1.py:440);
   * step C does not compute weight gradients of the adversarial heads: they are zeroed at the start of the
     next step A (train1.py:372-376) before any optimizer reads them;
+  * steps B and C run the backbone, the neck and the main head ONCE on the target batch: step B only updates the
+    adversarial heads (train1.py:434-436), so the second forward of the reference (train1.py:441) recomputes bit-identical
+    features f_t and y_t; step C re-uses them (with their autograd graph) and the BatchNorm layers of that shared part
+    apply their running-stat update twice (mi355_bn_train_fwd stat_updates=2), as two forwards would;
   * pseudo-labels, arg-max, KL and PCK stay on the device (the reference round-trips through numpy 12x / iteration).
 Data parallelism: one process per GPU; the flat gradient buffers of the optimizers about to step are
 all-reduced (mean) over the default process group between the backward and the optimizer kernels.
@@ -63,7 +67,14 @@ class DAStep:
         m, c, to = self.model, self.crit, self.trade_off
         for k in ('h_adv', 'h_adv2', 'h_adv3'):
             self.opt[k].zero_grad()
-        y_t, y_t_adv, y_t_adv2, y_t_adv3, _ = m(b['x_t'], detach_features=self.skip)
+        if self.skip:
+            with _rt.bn_updates(2):               # this forward also stands for step C's (identical) one
+                f_t = m.features(b['x_t'])
+                y_t = m.head(f_t).detach()        # only ever used detached (pseudo-labels) in B and C
+            self._shared = (f_t, y_t)
+            y_t_adv, y_t_adv2, y_t_adv3 = m.adv_heads(f_t.detach())
+        else:
+            y_t, y_t_adv, y_t_adv2, y_t_adv3, _ = m(b['x_t'])
         loss1 = to * c['rd1'](y_t, y_t_adv3, b['w_t'], mode='max')
         H = y_t.shape[-1]
         target5 = ops.bilinear_up(y_t_adv3.detach(), H, 0.5)               # 0.5 * up(y_adv3) ...
@@ -87,7 +98,12 @@ class DAStep:
             for p in self._adv_params:
                 p.requires_grad_(False)
         try:
-            y_t, y_t_adv, y_t_adv2, y_t_adv3, _ = m(b['x_t'])
+            if self.skip:
+                f_t, y_t = self._shared
+                self._shared = None
+                y_t_adv, y_t_adv2, y_t_adv3 = m.adv_heads(f_t)
+            else:
+                y_t, y_t_adv, y_t_adv2, y_t_adv3, _ = m(b['x_t'])
             loss1 = to * c['rd2'](y_t, y_t_adv2, None, b['w_t'], mode='min')
             loss2 = to * c['rd'](y_t, y_t_adv, None, b['w_t'], mode='min')
             loss_gt = 0.3 * loss1 + 1 * loss2

@@ -154,7 +154,7 @@ class _BnFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, gamma, beta, residual, mod, relu):
         y, mean, invstd = ops.bn_train_fwd(x, residual, gamma, beta, mod.running_mean, mod.running_var,
-                                           mod.num_batches_tracked, mod.eps, mod.momentum, relu)
+                                           mod.num_batches_tracked, mod.eps, mod.momentum, relu, _rt.bn_stat_updates)
         ctx.relu = relu
         # the ReLU mask is recomputed from x in backward unless a residual was added (then it needs y)
         keep_y = relu and (residual is not None or _MASK_FROM_Y)

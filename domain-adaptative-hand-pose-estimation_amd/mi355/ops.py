@@ -108,7 +108,7 @@ def colsum(dy, out, accumulate):
 
 
 # ---------------------------------------------------------------- batch norm
-def bn_train_fwd(x, residual, gamma, beta, running_mean, running_var, nbt, eps, momentum, relu):
+def bn_train_fwd(x, residual, gamma, beta, running_mean, running_var, nbt, eps, momentum, relu, stat_updates=1):
     _chk_dev(x, gamma)
     N, C, H, W = x.shape
     rows = N * H * W
@@ -117,7 +117,7 @@ def bn_train_fwd(x, residual, gamma, beta, running_mean, running_var, nbt, eps, 
     invstd = torch.empty(C, dtype=torch.float32, device=x.device)
     ws = workspace(load().mi355_bn_workspace(rows, C), x.device)
     call('mi355_bn_train_fwd', ptr(x), ptr(residual), ptr(y), ptr(gamma), ptr(beta), ptr(running_mean),
-         ptr(running_var), ptr(nbt), ptr(mean), ptr(invstd), rows, C, float(eps), float(momentum), int(relu),
+         ptr(running_var), ptr(nbt), ptr(mean), ptr(invstd), rows, C, float(eps), float(momentum), int(stat_updates), int(relu),
          dtype_code(x.dtype), ptr(ws), ws.numel(), stream_ptr())
     return y, mean, invstd
 

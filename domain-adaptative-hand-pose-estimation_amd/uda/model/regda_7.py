@@ -99,15 +99,20 @@ class PoseResNetx9(nn.Module):
                 return self.upsampling(self.backbone(x))
         return self.upsampling(self.backbone(x))
 
+    def adv_heads(self, f):
+        """The three cascaded adversarial heads behind the gradient layer: f -> (y_adv, y_adv2, y_adv3)."""
+        f_adv = self.gl_layer(f)
+        y_adv = self.head_adv(f_adv)
+        y_adv2 = self.head_adv2(f_adv, y_adv)
+        y_adv3 = self.head_adv3(f_adv, y_adv2)
+        return y_adv, y_adv2, y_adv3
+
     def forward(self, x, detach_features=False):
         f = self.features(x, detach_features)
         if not (self.training or self._always_tuple):
             return self.head(f)             # eval: the reference also runs the adv heads and drops them
-        f_adv = self.gl_layer(f)
         y = self.head(f)
-        y_adv = self.head_adv(f_adv)
-        y_adv2 = self.head_adv2(f_adv, y_adv)
-        y_adv3 = self.head_adv3(f_adv, y_adv2)
+        y_adv, y_adv2, y_adv3 = self.adv_heads(f)
         return y, y_adv, y_adv2, y_adv3, f
 
     def get_parameters(self, lr=1.):

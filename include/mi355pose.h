@@ -87,6 +87,9 @@ int mi355_colsum(const void* dy, float* out, long rows, int C, int dtype, int ac
  * the UNBIASED variance, eps 1e-5.
  *   y = relu?( (x-mean)*invstd*gamma + beta + residual? )
  * save_mean / save_invstd: fp32 [C] outputs consumed by mi355_bn_bwd.
+ * stat_updates: how many times the running-stat momentum update (and num_batches_tracked += 1) is applied: 1 normally;
+ *   2 when one forward stands for two identical forwards of the reference (train1.py:405 and :441 run the unchanged
+ *   backbone / neck / main head twice on the same target batch).
  * bwd: dy_eff = relu ? dy*(y>0) : dy ; dx = gamma*invstd*(dy_eff - mean(dy_eff) - xhat*mean(dy_eff*xhat));
  *      dresidual (nullable) = dy_eff ; dgamma/dbeta (=|+=).
  *      With relu and y == NULL the mask is recomputed from x (valid when the forward had no residual): one
@@ -96,7 +99,7 @@ size_t mi355_bn_workspace(long rows, int C);
 int mi355_bn_train_fwd(const void* x, const void* residual, void* y, const float* gamma, const float* beta,
                        float* running_mean, float* running_var, int64_t* num_batches_tracked,
                        float* save_mean, float* save_invstd, long rows, int C, float eps, float momentum,
-                       int relu, int dtype, void* ws, size_t ws_bytes, void* stream);
+                       int stat_updates, int relu, int dtype, void* ws, size_t ws_bytes, void* stream);
 int mi355_bn_eval_fwd(const void* x, const void* residual, void* y, const float* gamma, const float* beta,
                       const float* running_mean, const float* running_var, long rows, int C, float eps,
                       int relu, int dtype, void* stream);

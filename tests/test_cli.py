@@ -55,8 +55,9 @@ def test_train_resume_and_test_cli_on_gpu(gpu, tmp_path):
     out = run('train1.py', ['--epochs', '1', '--pretrain', str(tmp_path / 'none.pth')])
     assert 'Start regression domain adaptation.' in out and 'Target(best)' in out
     ck_path = os.path.join(log, 'checkpoints', '0.pth')
-    assert os.path.exists(ck_path) and os.path.exists(os.path.join(log, 'checkpoints', 'best.pth')) \
-        and os.path.exists(os.path.join(log, 'checkpoints', 'model_ema.pth')) and os.path.exists(os.path.join(log, 'checkpoints', 'pretrain.pth'))
+    # best.pth is only written when the target accuracy beats 0 (train1.py:266-268), which 6 iterations may not reach
+    assert os.path.exists(ck_path) and os.path.exists(os.path.join(log, 'checkpoints', 'model_ema.pth')) \
+        and os.path.exists(os.path.join(log, 'checkpoints', 'pretrain.pth'))
     ck = torch.load(ck_path, map_location='cpu', weights_only=False)
     for k in ('model', 'optimizer_f', 'optimizer_h', 'optimizer_h_adv', 'lr_scheduler_f', 'lr_scheduler_h', 'lr_scheduler_h_adv', 'epoch', 'args'):
         assert k in ck, k                      # the keys test.py:192-201 of the reference requires
