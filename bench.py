@@ -43,10 +43,14 @@ def parse():
     ap.add_argument('--image-size', type=int, default=256)
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f32'])
     ap.add_argument('--no-graph', action='store_true', help='launch eagerly instead of replaying HIP graphs')
+    ap.add_argument('--graph', action='store_true', help='replay HIP graphs also with more than one rank (default there: eager; '
+                    'at B=64 the iteration is GPU-bound either way: 44.72 ms replayed vs 44.75 ms eager)')
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--cpu-baseline-batch', type=int, default=4)
     ap.add_argument('--cpu-baseline-iters', type=int, default=3)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'], help='nccl = RCCL over xGMI (default); gloo only to rehearse the '
+                    'multi-process path on one GPU (all ranks on device 0)')
     return ap.parse_args()
 
 
@@ -101,11 +105,15 @@ def main():
             raise SystemExit('launch with torch.distributed.run --nproc-per-node %d for --gpus %d' % (args.gpus, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X: the HIP path has no CPU fallback')
-    torch.cuda.set_device(local_rank)
-    dev = torch.device('cuda', local_rank)
+    dev_index = local_rank if args.backend == 'nccl' else 0
+    torch.cuda.set_device(dev_index)
+    dev = torch.device('cuda', dev_index)
     if world > 1:
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        dist.init_process_group('nccl', device_id=dev)
+        if args.backend == 'nccl':
+            dist.init_process_group('nccl', device_id=dev)
+        else:
+            dist.init_process_group('gloo')
 
     import mi355
     from mi355 import ops
@@ -122,8 +130,8 @@ def main():
     backbone = models.__dict__[args.arch](pretrained=False)   # random init: no checkpoints offline
     model = PoseResNetx9(backbone, Upsampling(backbone.out_features), 256, 21, num_head_layers=2, finetune=True).to(dev)
     if world > 1:
-        for t in list(model.parameters()) + list(model.buffers()):
-            dist.broadcast(t.data, 0)
+        from mi355.da_step import broadcast_module
+        broadcast_module(model, src=0)
     step, opts, scheds = build_training(model, heatmap_size=S // 4)
     batch = make_batch(B, S, S // 4, seed=1 + rank, device=dev)
 
@@ -141,7 +149,8 @@ def main():
     for _ in range(n_eager):
         step.run(batch); tick()
     log('eager warm-up done')
-    if not args.no_graph:
+    use_graph = (not args.no_graph) and (world == 1 or args.graph)
+    if use_graph:
         step.capture(batch, warmup=0)
         log('graphs captured')
     for _ in range(max(0, args.warmup - n_eager)):
@@ -165,7 +174,8 @@ def main():
     # ---- roofline of the dominant kernel family (MFMA implicit-GEMM conv: gather + wgrad kernels), rank 0:
     # the same K steps again, eagerly, every conv launch bracketed by hipEvents on its stream.
     roof = None
-    if not args.no_roofline and rank == 0:
+    if not args.no_roofline:
+        # every rank runs these steps (they contain the gradient all-reduces); rank 0's events are the ones reported
         step.graphs = None
         n_prof = min(args.steps, 5)
         ops.prof_reset(); ops.prof_enable(True)
@@ -173,6 +183,7 @@ def main():
             step.run(batch); tick()
         torch.cuda.synchronize()
         ops.prof_enable(False)
+    if not args.no_roofline and rank == 0:
         ms, launches, flops = ops.prof_read()
         log('roofline pass done')
         # executed -> algorithmic FLOPs: the 3-channel stem runs padded to one 16-byte chunk (8 bf16 / 4 fp32 channels)
@@ -202,7 +213,7 @@ def main():
                                    'adversarial multiscale-fusion heads, %dx%d, batch %d source + %d target per GPU, '
                                    'random init, synthetic batches' % (args.arch, S, S, B, B),
                        'arch': args.arch, 'image_size': S, 'per_gpu_batch': B, 'global_batch': B * world,
-                       'parallelism': 'dp%d' % world, 'hip_graphs': not args.no_graph},
+                       'parallelism': 'dp%d' % world, 'hip_graphs': use_graph},
             'model_passes_per_s': round(3 * B * world / (ms_per_step * 1e-3), 2),
             'losses_last_step': losses,
         }

@@ -286,12 +286,19 @@ __global__ __launch_bounds__(256) void wgrad_gemm_kernel(const WgradArgs p) {
   constexpr int CPR = 128 / CH;                      // chunks per 128-wide tile row
   constexpr int RPT = BKM * CPR / 256;               // rows per thread per operand
   constexpr int ROWB = 128 * (int)sizeof(T);         // LDS row bytes
-  __shared__ __attribute__((aligned(16))) char smem[2 * BKM * ROWB];
+  __shared__ __attribute__((aligned(16))) char smem[2 * BKM * ROWB + 2 * BKM * 8];
   char* ys = smem;                 // DY tile [BKM][128 o]
   char* xs = smem + BKM * ROWB;    // X  tile [BKM][128 cols]
+  // pixel decode of the reduction rows, shared by the 16/32 lanes that stage one row: one thread per row decodes
+  // (n, oy, ox) for the NEXT tile while this one is multiplied -> {pixel index of the window origin, (iy0<<16)|ix0}
+  int2* rowinfo = reinterpret_cast<int2*>(smem + 2 * BKM * ROWB);   // [2][BKM]
 
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  const int tile = blockIdx.x;
+  // XCD-aware order: all tiles of one pixel range (split) are neighbours in the remapped id, i.e. share an XCD / L2,
+  // so the DY and X rows of that range are fetched into one L2 instead of eight
+  const int ntile = p.nto * p.nti;
+  const int lid = xcd_remap(blockIdx.x, gridDim.x);
+  const int split = lid / ntile, tile = lid - split * ntile;
   const int o0 = (tile / p.nti) * 128, c0 = (tile % p.nti) * 128;  // c0: flattened (tap, ci) column
   const int wm0 = (wave >> 1) * 64, wn0 = (wave & 1) * 64;
   const int lc = t % CPR, lr = t / CPR;
@@ -307,21 +314,31 @@ __global__ __launch_bounds__(256) void wgrad_gemm_kernel(const WgradArgs p) {
   const int tdy = tap / p.kw - p.pad, tdx = tap % p.kw - p.pad;
   const bool ook = (o0 + lc * CH) < p.Co;
 
-  const int mbeg = blockIdx.z * p.rows_per_split;
+  const int mbeg = split * p.rows_per_split;
   const int mend = min(p.M, mbeg + p.rows_per_split);
 
   uint4 rx[RPT], ry[RPT];
-  auto load_tile = [&](int mt0) {
+  const int toff = tdy * p.Wi + tdx;                       // this thread's tap as a pixel-index offset
+  auto decode_rows = [&](int mt0, int buf) {               // threads 0..BKM-1, one reduction row each
+    if (t < BKM) {
+      const unsigned m = (unsigned)(mt0 + t);
+      unsigned r = fd_div(m, p.dWo); int ox = (int)(m - r * p.Wo);
+      unsigned n = fd_div(r, p.dHo); int oy = (int)(r - n * p.Ho);
+      const int iy0 = oy * p.stride, ix0 = ox * p.stride;
+      rowinfo[buf * BKM + t] = make_int2(((int)n * p.Hi + iy0) * p.Wi + ix0, (iy0 << 16) | ix0);
+    }
+  };
+  auto load_tile = [&](int mt0, int buf) {
 #pragma unroll
     for (int i = 0; i < RPT; ++i) {
-      const int m = mt0 + lr + (256 / CPR) * i;
+      const int rr = lr + (256 / CPR) * i;
+      const int m = mt0 + rr;
       const bool mok = m < mend;
       ry[i] = buf_load16(rsY, (mok && ook) ? (m * p.Co + o0 + lc * CH) * (int)sizeof(T) : OOB_OFF);
-      unsigned r = fd_div((unsigned)m, p.dWo); int ox = m - r * p.Wo;
-      unsigned n = fd_div(r, p.dHo); int oy = r - n * p.Ho;
-      int iy = oy * p.stride + tdy, ix = ox * p.stride + tdx;
+      const int2 ri = rowinfo[buf * BKM + rr];
+      const int iy = (ri.y >> 16) + tdy, ix = (ri.y & 0xffff) + tdx;
       const bool xok = mok && colok && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
-      rx[i] = buf_load16(rsX, xok ? (((int)n * p.Hi + iy) * p.Wi + ix) * p.Ci * (int)sizeof(T) + ci * (int)sizeof(T) : OOB_OFF);
+      rx[i] = buf_load16(rsX, xok ? ((ri.x + toff) * p.Ci + ci) * (int)sizeof(T) : OOB_OFF);
     }
   };
   auto store_tile = [&]() {
@@ -346,26 +363,37 @@ __global__ __launch_bounds__(256) void wgrad_gemm_kernel(const WgradArgs p) {
   const int r31 = lane & 31, hi = lane >> 5;
   // tr16 lane roles: 16-lane group g reads a 4-row x 16-col block; lane 4q+p supplies row q, cols 4p..4p+3
   const int tg = lane >> 4, tq = (lane & 15) >> 2, tp = lane & 3;
-  if (mbeg < mend) load_tile(mbeg);
-  for (int mt0 = mbeg; mt0 < mend; mt0 += BKM) {
-    __syncthreads();   // previous tile's reads done
+  int trA[2][2], trB[2][2];     // LDS byte addresses of the tr16 reads of k-step 0: [sub-tile i][rows +0 / +4]
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int row = 8 * (tg >> 1) + tq + 4 * u;
+      trA[i][u] = swz256(row, (wm0 + i * 32) / 8 + 2 * (tg & 1) + (tp >> 1)) + 8 * (tp & 1);
+      trB[i][u] = swz256(row, (wn0 + i * 32) / 8 + 2 * (tg & 1) + (tp >> 1)) + 8 * (tp & 1);
+    }
+  decode_rows(mbeg, 0);
+  __syncthreads();
+  if (mbeg < mend) load_tile(mbeg, 0);
+  int buf = 0;
+  for (int mt0 = mbeg; mt0 < mend; mt0 += BKM, buf ^= 1) {
+    __syncthreads();   // previous tile's LDS reads done
     store_tile();
+    decode_rows(mt0 + BKM, buf ^ 1);
     __syncthreads();
-    if (mt0 + BKM < mend) load_tile(mt0 + BKM);
+    if (mt0 + BKM < mend) load_tile(mt0 + BKM, buf ^ 1);
     if constexpr (sizeof(T) == 2) {
 #pragma unroll
       for (int s = 0; s < BKM / 16; ++s) {
         bf16x8_t a[2], b[2];
-        const int row = 16 * s + 8 * (tg >> 1) + tq;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-          const int chA = (wm0 + i * 32) / 8 + 2 * (tg & 1) + (tp >> 1);
-          const int chB = (wn0 + i * 32) / 8 + 2 * (tg & 1) + (tp >> 1);
           typedef __attribute__((address_space(3))) bf16x4_t* lds4;
-          bf16x4_t a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4)(ys + swz256(row, chA) + 8 * (tp & 1)));
-          bf16x4_t a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4)(ys + swz256(row + 4, chA) + 8 * (tp & 1)));
-          bf16x4_t b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4)(xs + swz256(row, chB) + 8 * (tp & 1)));
-          bf16x4_t b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4)(xs + swz256(row + 4, chB) + 8 * (tp & 1)));
+          // the swizzle term of swz256 does not depend on s (16 rows = 4096 B per k-step): base + immediate offset
+          bf16x4_t a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4)(ys + trA[i][0] + s * 4096));
+          bf16x4_t a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4)(ys + trA[i][1] + s * 4096));
+          bf16x4_t b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4)(xs + trB[i][0] + s * 4096));
+          bf16x4_t b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4)(xs + trB[i][1] + s * 4096));
           a[i] = __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7);
           b[i] = __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7);
         }
@@ -391,7 +419,7 @@ __global__ __launch_bounds__(256) void wgrad_gemm_kernel(const WgradArgs p) {
       }
     }
   }
-  float* out = p.out + (size_t)blockIdx.z * p.slab_stride;
+  float* out = p.out + (size_t)split * p.slab_stride;
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -620,7 +648,7 @@ extern "C" int mi355_conv_wgrad(const mi355_conv_desc* d, const void* x, const v
   { const long esz = d->dtype == MI355_BF16 ? 2 : 4; a.x_bytes = (unsigned)((long)d->N * d->Hi * d->Wi * d->Ci * esz); a.dy_bytes = (unsigned)((long)a.M * d->Co * esz); }
   {
     ProfScope ps(st, 2.0 * a.M * (double)d->Co * w.ldw);
-    dim3 grid(w.nto * w.nti, 1, w.S);
+    dim3 grid(w.nto * w.nti * w.S);
     if (d->dtype == MI355_BF16) hipLaunchKernelGGL(wgrad_gemm_kernel<bf16_t>, grid, dim3(256), 0, st, a);
     else hipLaunchKernelGGL(wgrad_gemm_kernel<float>, grid, dim3(256), 0, st, a);
     MI_CHECK_LAUNCH("wgrad_gemm");

@@ -34,6 +34,20 @@ def _allreduce_mean(bufs):
             b.div_(ws)
 
 
+def broadcast_module(module, src=0):
+    """Rank `src`'s parameters and buffers to every rank.  Conv weights are strided (conv-form) views: the collective
+    runs on their dense memory-order view."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return
+    for t in list(module.parameters()) + list(module.buffers()):
+        d = t.data
+        if d.dim() == 4 and not d.is_contiguous():
+            d = d.permute(0, 2, 3, 1)
+        if not d.is_contiguous():
+            raise RuntimeError('cannot broadcast a non-dense tensor of shape %s' % (tuple(t.shape),))
+        dist.broadcast(d, src)
+
+
 class DAStep:
     """Holds the static batch buffers and runs A/B/C.  ``optimizers`` = dict with keys f, h, h_adv, h_adv2,
     h_adv3 (FusedSGD or any torch optimizer), ``criteria`` = dict with keys kl, rd (x6), rd2 (x5), rd1 (x1)."""
