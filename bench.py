@@ -73,6 +73,18 @@ def host_cores():
     return max(1, min(n, 64))
 
 
+def pmc_traffic(args):
+    """HBM bytes per launch of the conv family measured offline with rocprofv3 PMC passes on this same command
+    (profiles/r01_pmc_traffic.json: corrected as MI355X_MICROARCH.md prescribes, FETCH_SIZE doubled); null for
+    configurations that were not profiled."""
+    try:
+        rec = json.load(open(os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')))
+        key = '%s_%d_b%d_%s' % (args.arch, args.image_size, args.batch_size, args.dtype)
+        return rec['configs'][key]['conv_family_bytes_per_launch']
+    except Exception:
+        return None
+
+
 def cpu_baseline(arch, image_size, batch, iters):
     """The CPU oracle (pure-torch fp32 restatement of the reference iteration) on the host cores."""
     from oracle.train_step import build_model, DATrainer
@@ -184,18 +196,19 @@ def main():
         torch.cuda.synchronize()
         ops.prof_enable(False)
     if not args.no_roofline and rank == 0:
-        ms, launches, flops = ops.prof_read()
+        ms, launches, flops, abytes = ops.prof_read()
         log('roofline pass done')
         # executed -> algorithmic FLOPs: the 3-channel stem runs padded to one 16-byte chunk (8 bf16 / 4 fp32 channels)
         cpad = 8 if args.dtype == 'bf16' else 4
         stem_m = B * (S // 2) * (S // 2)
-        stem_excess = 2.0 * stem_m * 64 * 49 * (cpad - 3) * 5 * n_prof     # 3 fwd + 2 wgrad launches / iteration
+        stem_excess = 2.0 * stem_m * 64 * 49 * (cpad - 3) * 4 * n_prof     # 2 fwd (A, shared B+C) + 2 wgrad (A, C) launches / iteration
         algo = flops - stem_excess
         ach = algo / (ms * 1e-3) / 1e12
         peak = PEAK_TFLOPS[args.dtype]
         roof = {'bound': 'mfma', 'kernel': 'gather_gemm_kernel + wgrad_gemm_kernel (implicit-GEMM conv family)',
                 'achieved': round(ach, 2), 'peak': peak, 'unit': 'TFLOP/s', 'frac': round(ach / peak, 4),
-                'traffic': None, 'launches_per_step': launches // n_prof,
+                'traffic': pmc_traffic(args), 'traffic_unit': 'bytes per launch (rocprofv3 PMC: 2*FETCH_SIZE + WRITE_SIZE, separate passes)',
+                'algorithmic_bytes_per_launch': round(abytes / launches), 'launches_per_step': launches // n_prof,
                 'algorithmic_gflop_per_launch': round(algo / launches / 1e9, 3),
                 'avg_launch_us': round(ms * 1e3 / launches, 2),
                 'conv_ms_per_step': round(ms / n_prof, 3)}

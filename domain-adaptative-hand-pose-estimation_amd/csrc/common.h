@@ -115,6 +115,6 @@ __device__ inline unsigned fd_div(unsigned n, const FastDiv& f) {
 // ---- profiling (conv family) -----------------------------------------------------------
 struct ProfScope {
   hipStream_t s; bool on; int slot;
-  ProfScope(hipStream_t st, double flops);
+  ProfScope(hipStream_t st, double flops, double bytes = 0.0);
   ~ProfScope();
 };

@@ -6,6 +6,7 @@
 // 128-byte rows with an XOR swizzle so that ds_read_b128 fragment reads are conflict-free.
 // bf16: v_mfma_f32_32x32x16_bf16, fp32 accumulate.  f32: v_mfma_f32_32x32x2_f32 (exact fp32, parity path).
 #include "common.h"
+#include <stdlib.h>
 
 #define MAX_TAPS 52
 struct Tap { int8_t dy, dx; int16_t widx; };
@@ -485,8 +486,14 @@ static int dispatch_gather(GatherArgs& a, hipStream_t st) {
   }
   const bool small = (a.Ci / CH) < 8;
   double flops = 2.0 * a.M * (double)a.Nout * a.ntaps * a.Ci;
-  ProfScope ps(st, flops);
+  // algorithmic bytes: every input element, weight and output element once
+  ProfScope ps(st, flops, (double)a.a_bytes + (double)a.b_bytes * a.ntaps / (a.ldb / a.Ci) + (double)a.M * a.Nout * sizeof(T));
+  static const int force = getenv("MI355_TILE") ? atoi(getenv("MI355_TILE")) : -1;   // experiment switch
   if (small) { launch_gather<T, 128, 64, true>(a, st); }
+  else if (force == 0) launch_gather<T, 128, 128, false>(a, st);
+  else if (force == 1) launch_gather<T, 64, 128, false>(a, st);
+  else if (force == 2) launch_gather<T, 128, 64, false>(a, st);
+  else if (force == 3) launch_gather<T, 64, 64, false>(a, st);
   else {
     const long t128 = (long)cdiv(a.M, 128) * cdiv(a.Nout, 128);
     if (a.Nout <= 64) {
@@ -540,7 +547,7 @@ static int heatmap_conv(const void* x, const void* w, const float* bias, float* 
   a.kchunks = 1 << a.cshift;
   a.a_bytes = (unsigned)((long)N * HW * C * (long)sizeof(T));
   a.b_bytes = (unsigned)((long)K * C * (long)sizeof(T));
-  ProfScope ps(st, 2.0 * a.M * (double)K * C);
+  ProfScope ps(st, 2.0 * a.M * (double)K * C, (double)a.a_bytes + a.b_bytes + 4.0 * a.M * K);
   launch_gather<T, 128, 32, false, 4, 1, true>(a, st);
   MI_CHECK_LAUNCH("conv1x1_heatmap");
   return MI355_OK;
@@ -647,7 +654,7 @@ extern "C" int mi355_conv_wgrad(const mi355_conv_desc* d, const void* x, const v
   a.dWo = make_fastdiv(d->Wo); a.dHo = make_fastdiv(d->Ho);
   { const long esz = d->dtype == MI355_BF16 ? 2 : 4; a.x_bytes = (unsigned)((long)d->N * d->Hi * d->Wi * d->Ci * esz); a.dy_bytes = (unsigned)((long)a.M * d->Co * esz); }
   {
-    ProfScope ps(st, 2.0 * a.M * (double)d->Co * w.ldw);
+    ProfScope ps(st, 2.0 * a.M * (double)d->Co * w.ldw, (double)a.x_bytes + (double)a.dy_bytes + 4.0 * d->Co * w.ldw);
     dim3 grid(w.nto * w.nti * w.S);
     if (d->dtype == MI355_BF16) hipLaunchKernelGGL(wgrad_gemm_kernel<bf16_t>, grid, dim3(256), 0, st, a);
     else hipLaunchKernelGGL(wgrad_gemm_kernel<float>, grid, dim3(256), 0, st, a);

@@ -66,7 +66,7 @@ SIGNATURES = {
     'mi355_prof_enable': (_I, [_I]),
     'mi355_prof_reset': (_I, []),
     'mi355_prof_read': (_I, [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_long),
-                             ctypes.POINTER(ctypes.c_double)]),
+                             ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]),
 }
 
 

@@ -309,6 +309,6 @@ def prof_reset():
 
 
 def prof_read():
-    ms, n, fl = ctypes.c_double(), ctypes.c_long(), ctypes.c_double()
-    call('mi355_prof_read', ctypes.byref(ms), ctypes.byref(n), ctypes.byref(fl))
-    return ms.value, n.value, fl.value
+    ms, n, fl, by = ctypes.c_double(), ctypes.c_long(), ctypes.c_double(), ctypes.c_double()
+    call('mi355_prof_read', ctypes.byref(ms), ctypes.byref(n), ctypes.byref(fl), ctypes.byref(by))
+    return ms.value, n.value, fl.value, by.value

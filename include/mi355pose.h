@@ -200,7 +200,7 @@ int mi355_cast_f32(const float* in, void* out, long n, int dtype, void* stream);
  * mi355_prof_read synchronises the recorded events and returns totals since the last reset. */
 int mi355_prof_enable(int on);
 int mi355_prof_reset(void);
-int mi355_prof_read(double* total_ms, long* launches, double* flops);
+int mi355_prof_read(double* total_ms, long* launches, double* flops, double* algorithmic_bytes);
 
 #ifdef __cplusplus
 }
