@@ -369,3 +369,21 @@ def test_errors_are_loud(gpu):
     x = torch.zeros(1, 8, 8, 24, dtype=torch.bfloat16, device=gpu).permute(0, 3, 1, 2)
     with pytest.raises(mi355.Mi355Error):
         ops.conv_fwd(desc, x, torch.zeros(64 * 9 * 24, dtype=torch.bfloat16, device=gpu))
+
+
+def test_device_label_generation_matches_generate_target(gpu):
+    """utils.labels.generate_target_device vs the oracle's restatement of uda/dataset/util.py:9-68, bit-exact, incl.
+    centres on the border, outside the map, and invisible joints."""
+    from utils.labels import generate_target_device
+    from oracle.losses import generate_target
+    rng = np.random.default_rng(5)
+    B, K = 3, 21
+    kp = rng.uniform(-12, 268, size=(B, K, 2))
+    kp[0, 0] = (0.0, 0.0); kp[0, 1] = (255.9, 255.9); kp[0, 2] = (3.9, 250.0); kp[0, 3] = (258.0, 10.0); kp[0, 4] = (-1.9, 30.0)
+    vis = (rng.random((B, K, 1)) < 0.8).astype(np.float32)
+    ref_t = np.zeros((B, K, 64, 64), np.float32); ref_w = np.zeros((B, K, 1), np.float32)
+    for b in range(B):
+        ref_t[b], ref_w[b] = generate_target(kp[b], vis[b], (64, 64), 2, (256, 256))
+    t, w = generate_target_device(torch.from_numpy(kp).to(gpu), torch.from_numpy(vis).to(gpu))
+    assert np.array_equal(w.cpu().numpy(), ref_w)
+    assert np.array_equal(t.cpu().numpy(), ref_t)
