@@ -56,23 +56,26 @@ template <> struct MmaTraits<bf16_t> { static constexpr int BK = 64; static cons
 template <> struct MmaTraits<float> { static constexpr int BK = 32; static constexpr int CH = 4; };
 
 #define GATHER_STAGES 1     // one LDS stage: the pipeline depth lives in registers (see the K loop)
-template <typename T, int BM, int BN>
+template <typename T, int BM, int BN, int STAGES = 1>
 struct GatherSmem {
   static constexpr int kStage = (BM + BN) * 128;
   static constexpr int kOutStride = BN * (int)sizeof(T) + 16;
   static constexpr int kOut = BM * kOutStride;
-  static constexpr int kBytes = (GATHER_STAGES * kStage > kOut ? GATHER_STAGES * kStage : kOut) + BM * 4;
+  static constexpr int kBytes = (STAGES * kStage > kOut ? STAGES * kStage : kOut) + BM * 4;
 };
 
 // WGM x WGN waves per workgroup (64 lanes each); every wave owns a (BM/WGM) x (BN/WGN) sub-tile.
 // HM_OUT: the result is written as NCHW fp32 heat-maps [image][Nout][hw] (the 1x1 conv to the K=21 key-point maps).
-template <typename T, int BM, int BN, bool SMALL_C, int WGM = 2, int WGN = 2, bool HM_OUT = false>
+// DMA: K-tiles travel global -> LDS directly (buffer_load ... lds, 1 KiB per wave-instruction, out-of-range lanes deliver
+//      zeros) into a 2-stage ring: no staging registers, no ds_write, one barrier per K-tile.
+template <typename T, int BM, int BN, bool SMALL_C, int WGM = 2, int WGN = 2, bool HM_OUT = false, bool DMA = false>
 __global__ __launch_bounds__(64 * WGM * WGN) void gather_gemm_kernel(const GatherArgs p) {
   constexpr int CH = MmaTraits<T>::CH;
   constexpr int NTHR = 64 * WGM * WGN, RPP = NTHR / 8;      // rows staged per pass (8 lanes = one 128-byte row)
   constexpr int WM = BM / WGM, WN = BN / WGN, MT = WM / 32, NT = WN / 32;
   constexpr int RA = BM / RPP, RB = BN / RPP;
-  using SM = GatherSmem<T, BM, BN>;
+  using SM = GatherSmem<T, BM, BN, DMA ? 2 : 1>;
+  static_assert(!DMA || !SMALL_C, "the LDS-DMA pipeline is built for the large-channel path");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   int* row_off = reinterpret_cast<int*>(smem + SM::kBytes - BM * 4);
 
@@ -128,8 +131,36 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gather_gemm_kernel(const Gathe
       rb[i] = buf_load16(rsB, (okq && n < p.Nout) ? (n * p.ldb + koff) * (int)sizeof(T) : OOB_OFF);
     }
   };
-  char* const as = smem;
-  char* const bs = smem + BM * 128;
+  // LDS-DMA issue of K-tile kt into ring stage `stage`: lane (row lr, physical chunk lc) fetches the logical chunk
+  // lc ^ ((row>>1)&7), so the linear 1-KiB image each wave-instruction writes IS the swizzled tile (swizzle on the source)
+  const int lcs = lc ^ ((lr >> 1) & 7);
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  auto dma_tile = [&](int kt, int stage) {
+    const int q0 = kt * 8, tap = q0 >> p.cshift;
+    const int cc = ((q0 & cmask) + lcs) * CH;
+    const Tap tp = p.taps[tap];
+    const int koff = (int)tp.widx * p.Ci + cc;
+#if defined(__HIP_DEVICE_COMPILE__)    // (the host pass must still be able to emit the kernel stub)
+    typedef __attribute__((address_space(3))) void* ldsp;
+    char* sa = smem + stage * SM::kStage + wave_u * 1024;
+    char* sb = sa + BM * 128;
+#pragma unroll
+    for (int i = 0; i < RA; ++i) {
+      int iy = iy0[i] + tp.dy, ix = ix0[i] + tp.dx;
+      bool ok = (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (ldsp)(sa + i * RPP * 128), 16,
+                                               ok ? ((abase[i] + iy * p.Wi + ix) * p.Ci + cc) * (int)sizeof(T) : OOB_OFF, 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < RB; ++i) {
+      int n = n0 + lr + RPP * i;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (ldsp)(sb + i * RPP * 128), 16,
+                                               n < p.Nout ? (n * p.ldb + koff) * (int)sizeof(T) : OOB_OFF, 0, 0, 0);
+    }
+#endif
+  };
+  char* as = smem;
+  char* bs = smem + BM * 128;
   auto store_tile = [&](const uint4 (&ra)[RA], const uint4 (&rb)[RB]) {
 #pragma unroll
     for (int i = 0; i < RA; ++i) *reinterpret_cast<uint4*>(as + swz128(lr + RPP * i, lc)) = ra[i];
@@ -179,13 +210,28 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gather_gemm_kernel(const Gathe
   };
 
   const int nk = (p.kchunks + 7) >> 3;
-  load_tile(0, ra0, rb0);
-  for (int kt = 0; kt < nk; ++kt) {
-    __syncthreads(); store_tile(ra0, rb0); __syncthreads();
-    if (kt + 1 < nk) load_tile(kt + 1, ra0, rb0);
-    __builtin_amdgcn_s_setprio(1);
-    compute();
-    __builtin_amdgcn_s_setprio(0);
+  if constexpr (DMA) {
+    dma_tile(0, 0);
+    for (int kt = 0; kt < nk; ++kt) {
+#if defined(__HIP_DEVICE_COMPILE__)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's pieces of tile kt have landed in LDS
+#endif
+      __syncthreads();                                      // everyone's have; stage (kt+1)&1 is no longer being read
+      if (kt + 1 < nk) dma_tile(kt + 1, (kt + 1) & 1);
+      as = smem + (kt & 1) * SM::kStage; bs = as + BM * 128;
+      __builtin_amdgcn_s_setprio(1);
+      compute();
+      __builtin_amdgcn_s_setprio(0);
+    }
+  } else {
+    load_tile(0, ra0, rb0);
+    for (int kt = 0; kt < nk; ++kt) {
+      __syncthreads(); store_tile(ra0, rb0); __syncthreads();
+      if (kt + 1 < nk) load_tile(kt + 1, ra0, rb0);
+      __builtin_amdgcn_s_setprio(1);
+      compute();
+      __builtin_amdgcn_s_setprio(0);
+    }
   }
   __syncthreads();
 
@@ -460,11 +506,11 @@ __global__ void zero_fill_kernel(uint4* __restrict__ p, size_t n16) {
 // ------------------------------------------------------------------------------------ host side
 static int ilog2_exact(int v) { int s = 0; while ((1 << s) < v) ++s; return ((1 << s) == v) ? s : -1; }
 
-template <typename T, int BM, int BN, bool SMALL_C, int WGM = 2, int WGN = 2, bool HM_OUT = false>
+template <typename T, int BM, int BN, bool SMALL_C, int WGM = 2, int WGN = 2, bool HM_OUT = false, bool DMA = false>
 static void launch_gather(GatherArgs& a, hipStream_t st) {
   a.ntm = cdiv(a.M, BM); a.ntn = cdiv(a.Nout, BN);
-  constexpr int smem = GatherSmem<T, BM, BN>::kBytes;
-  auto kern = gather_gemm_kernel<T, BM, BN, SMALL_C, WGM, WGN, HM_OUT>;
+  constexpr int smem = GatherSmem<T, BM, BN, DMA ? 2 : 1>::kBytes;
+  auto kern = gather_gemm_kernel<T, BM, BN, SMALL_C, WGM, WGN, HM_OUT, DMA>;
   static bool attr_set = false;   // raise the dynamic-LDS cap once per instantiation
   if (!attr_set) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem); attr_set = true; }
   hipLaunchKernelGGL(kern, dim3(a.ntm * a.ntn), dim3(64 * WGM * WGN), smem, st, a);
@@ -489,6 +535,7 @@ static int dispatch_gather(GatherArgs& a, hipStream_t st) {
   // algorithmic bytes: every input element, weight and output element once
   ProfScope ps(st, flops, (double)a.a_bytes + (double)a.b_bytes * a.ntaps / (a.ldb / a.Ci) + (double)a.M * a.Nout * sizeof(T));
   static const int force = getenv("MI355_TILE") ? atoi(getenv("MI355_TILE")) : -1;   // experiment switch
+  static const int dma_mode = getenv("MI355_DMA") ? atoi(getenv("MI355_DMA")) : 1;
   if (small) { launch_gather<T, 128, 64, true>(a, st); }
   else if (force == 0) launch_gather<T, 128, 128, false>(a, st);
   else if (force == 1) launch_gather<T, 64, 128, false>(a, st);
@@ -498,7 +545,11 @@ static int dispatch_gather(GatherArgs& a, hipStream_t st) {
     const long t128 = (long)cdiv(a.M, 128) * cdiv(a.Nout, 128);
     if (a.Nout <= 64) {
       if ((long)cdiv(a.M, 128) >= 512) launch_gather<T, 128, 64, false>(a, st); else launch_gather<T, 64, 64, false>(a, st);
-    } else if (t128 >= 512) launch_gather<T, 128, 128, false>(a, st);   // (128x256 tile with 8 waves measured slower: 687 vs 755 TFLOP/s)
+    } else if (sizeof(T) == 2 && getenv("MI355_T256") && a.Nout % 256 == 0 && (long)cdiv(a.M, 256) * (a.Nout / 256) >= 256) launch_gather<T, 256, 256, false, 2, 4>(a, st);
+    // LDS-DMA ring for K-heavy layers (>= 16 K-tiles): +9..12 % on the 3x3 / 4x4 convs, but -15 % on short-K 1x1 convs
+    // (2 blocks/CU instead of 3), so those keep the register-staged form.  MI355_DMA=0 disables, =2 forces (tests).
+    else if ((dma_mode == 2 && a.Nout > 64) || (dma_mode == 1 && t128 >= 512 && a.kchunks >= 128)) launch_gather<T, 128, 128, false, 2, 2, false, true>(a, st);
+    else if (t128 >= 512) launch_gather<T, 128, 128, false>(a, st);   // (128x256 tile with 8 waves measured slower: 687 vs 755 TFLOP/s)
     else if ((long)cdiv(a.M, 64) * cdiv(a.Nout, 128) >= 512) launch_gather<T, 64, 128, false>(a, st);
     else launch_gather<T, 64, 64, false>(a, st);
   }
