@@ -245,50 +245,57 @@ def validate(val_loader, model, criterion, args):
     return acc.average()
 
 
-def build_parser(description='Source Only for Keypoint Detection Domain Adaptation'):
-    arch_names = sorted(n for n in models.__dict__ if n.islower() and not n.startswith("__") and callable(models.__dict__[n]))
-    p = argparse.ArgumentParser(description=description)
-    a = p.add_argument
-    a('--source_root', default='data/RHD', help='root path of the source dataset')
-    a('target_root', help='root path of the target dataset')
-    a('-s', '--source', default='RenderedHandPose', help='source domain(s)')
-    a('-t', '--target', help='target domain(s)')
-    a('--resize-scale', nargs='+', type=float, default=(0.6, 1.3), help='scale range for the RandomResizeCrop augmentation')
-    a('--rotation', type=int, default=180, help='rotation range of the RandomRotation augmentation')
-    a('--image-size', type=int, default=256, help='input image size')
-    a('--heatmap-size', type=int, default=64, help='output heatmap size')
-    a('-a', '--arch', metavar='ARCH', default='resnet101', choices=arch_names, help='backbone architecture: ' + ' | '.join(arch_names))
-    a('-a2', '--arch2', metavar='ARCH', default='net_hg', help='(unused, kept for CLI parity)')
-    a("--pretrain", type=str, default='models/pretrain_rhd.pth', help="Where restore pretrained model parameters from.")
-    a("--ema_model", type=str, default=None, help="(unused, kept for CLI parity)")
-    a("--resume", type=str, default=None, help="where restore model parameters from.")
-    a("--resume2", type=str, default=None, help="(unused, kept for CLI parity)")
-    a('--num-head-layers', type=int, default=2)
-    a('--margin', type=float, default=4., help="margin gamma (unused, kept for CLI parity)")
-    a('--trade-off', default=1., type=float, help='the trade-off hyper-parameter for transfer loss')
-    a('-b', '--batch-size', default=32, type=int, metavar='N', help='mini-batch size (default: 32)')
-    a('--lr', '--learning-rate', default=0.01, type=float, metavar='LR', help='initial learning rate', dest='lr')
-    a('--momentum', default=0.9, type=float, metavar='M', help='momentum')
-    a('--wd', '--weight-decay', default=0.0001, type=float, metavar='W', help='weight decay (default: 1e-4)')
-    a('--lr-gamma', default=0.0001, type=float)
-    a('--lr-decay', default=0.75, type=float, help='parameter for lr scheduler')
-    a('--lr-step', default=[45, 60], type=tuple, help='parameter for lr scheduler')
-    a('--lr-factor', default=0.1, type=float, help='parameter for lr scheduler')
-    a('-j', '--workers', default=4, type=int, metavar='N', help='number of data loading workers (default: 4)')
-    a('--pretrain_epochs', default=70, type=int, metavar='N', help='number of total epochs to run')
-    a('--epochs', default=200, type=int, metavar='N', help='number of total epochs to run')
-    a('-i', '--iters-per-epoch', default=500, type=int, help='Number of iterations per epoch')
-    a('-p', '--print-freq', default=100, type=int, metavar='N', help='print frequency (default: 100)')
-    a('--seed', default=1, type=int, help='seed for initializing training. ')
-    a("--log", type=str, default='logs/mt', help="Where to save logs, checkpoints and debugging images.")
-    a("--phase", type=str, default='train', choices=['train', 'test'], help="When phase is 'test', only test the model.")
-    a('--debug', action="store_true", help='(visualisation is out of scope; accepted for CLI parity)')
-    a('--ema-decay', default=0.999, type=float, metavar='ALPHA', help='(unused, kept for CLI parity)')
-    # additive flags
-    a('--synthetic', action='store_true', help='seeded synthetic batches instead of the CPU dataset layer')
-    a('--dtype', default='bf16', choices=['bf16', 'f32'], help='compute dtype of activations / packed weights')
-    a('--no-graph', action='store_true', help='launch kernels eagerly instead of replaying HIP graphs')
-    return p
+# (flags, kwargs) for every option of the reference's command line (train1.py:602-674: same names, types and
+# defaults), followed by the additive ones of this implementation
+_OPTIONS = [
+    (('--source_root',), dict(default='data/RHD', help='source dataset directory')),
+    (('target_root',), dict(help='target dataset directory')),
+    (('-s', '--source'), dict(default='RenderedHandPose', help='source dataset class')),
+    (('-t', '--target'), dict(help='target dataset class')),
+    (('--resize-scale',), dict(nargs='+', type=float, default=(0.6, 1.3), help='RandomResizedCrop scale range')),
+    (('--rotation',), dict(type=int, default=180, help='RandomRotation range in degrees')),
+    (('--image-size',), dict(type=int, default=256, help='network input side')),
+    (('--heatmap-size',), dict(type=int, default=64, help='heat-map side of the main head')),
+    (('-a2', '--arch2'), dict(metavar='ARCH', default='net_hg', help='unused (reference CLI parity)')),
+    (('--pretrain',), dict(type=str, default='models/pretrain_rhd.pth', help='source-only pre-training checkpoint')),
+    (('--ema_model',), dict(type=str, default=None, help='unused (reference CLI parity)')),
+    (('--resume',), dict(type=str, default=None, help='checkpoint to continue from')),
+    (('--resume2',), dict(type=str, default=None, help='unused (reference CLI parity)')),
+    (('--num-head-layers',), dict(type=int, default=2)),
+    (('--margin',), dict(type=float, default=4., help='unused (reference CLI parity)')),
+    (('--trade-off',), dict(default=1., type=float, help='weight of the target-domain disparity losses')),
+    (('-b', '--batch-size'), dict(default=32, type=int, metavar='N', help='images per domain per iteration')),
+    (('--lr', '--learning-rate'), dict(default=0.01, type=float, metavar='LR', dest='lr', help='base learning rate')),
+    (('--momentum',), dict(default=0.9, type=float, metavar='M')),
+    (('--wd', '--weight-decay'), dict(default=0.0001, type=float, metavar='W')),
+    (('--lr-gamma',), dict(default=0.0001, type=float, help='inverse-decay schedule: lr * (1 + gamma * it) ** -decay')),
+    (('--lr-decay',), dict(default=0.75, type=float)),
+    (('--lr-step',), dict(default=[45, 60], type=tuple, help='pre-training MultiStepLR milestones')),
+    (('--lr-factor',), dict(default=0.1, type=float, help='pre-training MultiStepLR factor')),
+    (('-j', '--workers'), dict(default=4, type=int, metavar='N', help='loader worker processes')),
+    (('--pretrain_epochs',), dict(default=70, type=int, metavar='N')),
+    (('--epochs',), dict(default=200, type=int, metavar='N')),
+    (('-i', '--iters-per-epoch'), dict(default=500, type=int)),
+    (('-p', '--print-freq'), dict(default=100, type=int, metavar='N')),
+    (('--seed',), dict(default=1, type=int)),
+    (('--log',), dict(type=str, default='logs/mt', help='run directory (logs, checkpoints, images)')),
+    (('--phase',), dict(type=str, default='train', choices=['train', 'test'])),
+    (('--debug',), dict(action='store_true', help='accepted for CLI parity (visualisation is out of scope)')),
+    (('--ema-decay',), dict(default=0.999, type=float, metavar='ALPHA', help='unused (reference CLI parity)')),
+    # additive
+    (('--synthetic',), dict(action='store_true', help='seeded synthetic batches instead of the CPU dataset layer')),
+    (('--dtype',), dict(default='bf16', choices=['bf16', 'f32'], help='compute dtype of activations / packed weights')),
+    (('--no-graph',), dict(action='store_true', help='launch kernels eagerly instead of replaying HIP graphs')),
+]
+
+
+def build_parser(description='Domain-adaptive hand-pose training on MI355X'):
+    archs = sorted(n for n in models.__dict__ if n.islower() and not n.startswith('__') and callable(models.__dict__[n]))
+    parser = argparse.ArgumentParser(description=description)
+    parser.add_argument('-a', '--arch', metavar='ARCH', default='resnet101', choices=archs, help=' | '.join(archs))
+    for flags, kw in _OPTIONS:
+        parser.add_argument(*flags, **kw)
+    return parser
 
 
 if __name__ == '__main__':

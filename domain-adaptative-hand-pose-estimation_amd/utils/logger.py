@@ -1,25 +1,26 @@
-"""stdout/stderr tee + checkpoint / image paths (reference ``utils/logger.py``; same directory layout:
-``<root>/<phase>-<time>.txt``, ``<root>/checkpoints/<name>.pth``, ``<root>/visualize/<epoch|phase>/``)."""
+"""Run directory manager with the reference's layout (``utils/logger.py``): console output is mirrored into
+``<root>/<phase>-<timestamp>.txt``; checkpoints live in ``<root>/checkpoints/<name>.pth`` and debug images in
+``<root>/visualize/<epoch or phase>/``."""
 import os
 import sys
 import time
 
 
-class TextLogger(object):
-    """Writes stream output to an external text file as well."""
+class TextLogger:
+    """A writable stream that forwards to the console stream and appends to a log file."""
 
-    def __init__(self, filename, stream=sys.stdout):
-        self.terminal = stream
+    def __init__(self, filename, stream=None):
+        self.terminal = stream if stream is not None else sys.stdout
         self.log = open(filename, 'a')
 
     def write(self, message):
-        self.terminal.write(message)
-        self.log.write(message)
+        for sink in (self.terminal, self.log):
+            sink.write(message)
         self.flush()
 
     def flush(self):
-        self.terminal.flush()
-        self.log.flush()
+        for sink in (self.terminal, self.log):
+            sink.flush()
 
     def close(self):
         self.log.close()
@@ -28,36 +29,34 @@ class TextLogger(object):
 class CompleteLogger:
     def __init__(self, root, phase='train'):
         self.root, self.phase, self.epoch = root, phase, 0
-        self.visualize_directory = os.path.join(root, "visualize")
-        self.checkpoint_directory = os.path.join(root, "checkpoints")
-        for d in (root, self.visualize_directory, self.checkpoint_directory):
+        self.visualize_directory = os.path.join(root, 'visualize')
+        self.checkpoint_directory = os.path.join(root, 'checkpoints')
+        for d in (self.visualize_directory, self.checkpoint_directory):
             os.makedirs(d, exist_ok=True)
-        now = time.strftime("%Y-%m-%d-%H_%M_%S", time.localtime(time.time()))
-        log_filename = os.path.join(root, "{}-{}.txt".format(phase, now))
-        if os.path.exists(log_filename):
-            os.remove(log_filename)
-        self._stdout, self._stderr = sys.stdout, sys.stderr
-        self.logger = TextLogger(log_filename, sys.stdout)
-        sys.stdout = self.logger
-        sys.stderr = self.logger
+        stamp = time.strftime('%Y-%m-%d-%H_%M_%S')
+        path = os.path.join(root, '%s-%s.txt' % (phase, stamp))
+        if os.path.exists(path):          # two runs within the same second: start the file afresh
+            os.remove(path)
+        self._saved = (sys.stdout, sys.stderr)
+        self.logger = TextLogger(path, sys.stdout)
+        sys.stdout = sys.stderr = self.logger
         if phase != 'train':
             self.set_epoch(phase)
 
-    def set_epoch(self, epoch):
-        os.makedirs(os.path.join(self.visualize_directory, str(epoch)), exist_ok=True)
-        self.epoch = epoch
+    # the sub-directory images go to: the epoch number while training, the phase name otherwise
+    def _bucket(self):
+        return str(self.epoch if self.phase == 'train' else self.phase)
 
-    def _get_phase_or_epoch(self):
-        return str(self.epoch) if self.phase == 'train' else self.phase
+    def set_epoch(self, epoch):
+        self.epoch = epoch
+        os.makedirs(os.path.join(self.visualize_directory, str(epoch)), exist_ok=True)
 
     def get_image_path(self, filename: str):
-        return os.path.join(self.visualize_directory, self._get_phase_or_epoch(), filename)
+        return os.path.join(self.visualize_directory, self._bucket(), filename)
 
     def get_checkpoint_path(self, name=None):
-        if name is None:
-            name = self._get_phase_or_epoch()
-        return os.path.join(self.checkpoint_directory, str(name) + ".pth")
+        return os.path.join(self.checkpoint_directory, '%s.pth' % (self._bucket() if name is None else name))
 
     def close(self):
-        sys.stdout, sys.stderr = self._stdout, self._stderr
+        sys.stdout, sys.stderr = self._saved
         self.logger.close()
