@@ -1,0 +1,132 @@
+"""Drop-in API behaviour on the GPU: the reference's call signatures, return types and error behaviour
+(uda.model / utils mirrors), checked against the oracle / golden vectors."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden
+from seeded import fill_module_, randn, rand, peaky_heatmaps, weights_bk
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True)
+def _f32_mode():
+    import mi355
+    mi355.set_compute_dtype('f32')
+    yield
+    mi355.set_compute_dtype('bf16')
+
+
+def test_numpy_decode_api_matches_golden(gpu):
+    """get_max_preds / accuracy keep the reference's numpy-in / numpy-out contract (utils/keypoint_detection.py:7-92)."""
+    from utils.keypoint_detection import get_max_preds, accuracy
+    g = golden('g4_argmax_accuracy')
+    hm = peaky_heatmaps(401, 3, 21, 64, 64).numpy()
+    hm[1, 0] = 0.5
+    hm[1, 1, 10, 7] = hm[1, 1, 40, 3] = 9.0
+    hm[2, 2, 63, 63] = 11.0
+    lab = np.maximum(peaky_heatmaps(402, 3, 21, 64, 64).numpy(), 0)
+    preds, maxvals = get_max_preds(hm)
+    assert isinstance(preds, np.ndarray) and preds.dtype == np.float32
+    assert np.array_equal(preds, g['preds']) and np.array_equal(maxvals, g['maxvals'])
+    acc, avg, cnt, pred = accuracy(hm, lab)
+    assert np.array_equal(acc, g['acc']) and avg == float(g['avg']) and cnt == int(g['cnt']) and np.array_equal(pred, g['pred'])
+    # torch CUDA tensors are accepted too (no host round trip of the maps)
+    acc2, avg2, cnt2, _ = accuracy(torch.from_numpy(hm).to(gpu), torch.from_numpy(lab).to(gpu))
+    assert np.array_equal(acc2, acc) and avg2 == avg and cnt2 == cnt
+    with pytest.raises(AssertionError):
+        get_max_preds(hm[0])            # 3-d input: same assertion as the reference
+
+
+def test_loss_api_and_errors(gpu):
+    from uda.model.loss import JointsKLLoss
+    from uda.model.regda_4 import PseudoLabelGenerator
+    from uda.model.regda_7 import RegressionDisparityx6, PseudoLabelGenerator01, RegressionDisparityx1
+    from oracle import losses as ol
+    B, K = 2, 21
+    y, y_adv = peaky_heatmaps(201, B, K, 64, 64), randn(202, B, K, 64, 64)
+    w = weights_bk(207, B, K)
+    rd = RegressionDisparityx6(PseudoLabelGenerator(K, 64, 64), JointsKLLoss(epsilon=1e-7))
+    with pytest.raises(AssertionError):
+        rd(y.to(gpu), y_adv.to(gpu), None, w.to(gpu), mode='sideways')     # regda_7.py:3610
+    # reduction='none' -> (B,) like the reference
+    lab = rand(205, B, K, 64, 64) * (rand(206, B, K, 64, 64) > 0.9)
+    got = JointsKLLoss(reduction='none')(y_adv.to(gpu), lab.to(gpu), w.to(gpu))
+    ref = ol.JointsKLLoss(reduction='none')(y_adv, lab, w)
+    assert tuple(got.shape) == (B,) and torch.allclose(got.cpu(), ref, rtol=1e-4)
+    # generator returns (ground_truth, ground_false) tensors on the prediction's device
+    gt, gf = PseudoLabelGenerator(K, 64, 64)(y.to(gpu))
+    gt_ref, gf_ref = ol.PseudoLabelGenerator(K, 64, 64)(y)
+    assert gt.device.type == 'cuda' and torch.equal(gt.cpu(), gt_ref) and torch.allclose(gf.cpu(), gf_ref, atol=2e-7)
+    rd1 = RegressionDisparityx1(PseudoLabelGenerator01(K), JointsKLLoss(epsilon=1e-7))
+    v = rd1(y.to(gpu), randn(204, B, K, 16, 16).to(gpu), w.to(gpu), mode='min')
+    assert v.dim() == 0 and rd1.ground_truth.shape == (B, K, 16, 16)
+
+
+def test_pose_resnet_pretrain_model_and_parameter_groups(gpu):
+    """PoseResNet (source-only pre-training, pose_resnet2.py:157-189) forward/backward vs the oracle, get_parameters()
+    groups, eval-mode return type of PoseResNetx9, GL step bookkeeping."""
+    import uda.model as models
+    from uda.model.pose_resnet2 import Upsampling, PoseResNet
+    from uda.model.regda_7 import PoseResNetx9, PoseResNetx10
+    from uda.model.loss import JointsKLLoss
+    from oracle.backbone import make_backbone
+    from oracle import pose as op, losses as ol
+    bb = models.resnet18()
+    m = PoseResNet(bb, Upsampling(bb.out_features), 256, 21, True)
+    rb = make_backbone('resnet18')
+    r = op.PoseResNet(rb, op.Upsampling(rb.out_features), 256, 21, True)
+    fill_module_(r, 31)
+    m.load_state_dict(r.state_dict())
+    m = m.to(gpu)
+    x = randn(32, 2, 3, 128, 128)
+    lab = rand(33, 2, 21, 32, 32) * (rand(34, 2, 21, 32, 32) > 0.8)
+    m.train(); r.train()
+    y = m(x.to(gpu)); y_ref = r(x)
+    assert float((y.detach().cpu() - y_ref.detach()).abs().max()) <= 1e-3 * float(y_ref.abs().max())
+    loss = JointsKLLoss()(y, lab.to(gpu)); loss.backward()
+    loss_ref = ol.JointsKLLoss()(y_ref, lab); loss_ref.backward()
+    assert abs(float(loss) - float(loss_ref)) <= 1e-4 * abs(float(loss_ref))
+    g, g_ref = m.head.weight.grad.cpu(), r.head.weight.grad
+    assert float((g - g_ref).norm() / g_ref.norm()) < 2e-2
+    groups = m.get_parameters(lr=0.5)
+    assert [gr['lr'] for gr in groups] == [0.05, 0.5, 0.5] and len(list(groups[0]['params'])) == len(list(bb.parameters()))
+    # DA model: 6 groups, eval returns a single tensor, x10 always the 5-tuple, step() advances lambda
+    bb2 = models.resnet18()
+    da = PoseResNetx9(bb2, Upsampling(bb2.out_features), 256, 21).to(gpu)
+    assert len(da.get_parameters(1.0)) == 6 and da.get_parameters(1.0)[0]['lr'] == 0.1
+    da.eval()
+    with torch.no_grad():
+        out = da(x.to(gpu))
+    assert torch.is_tensor(out) and tuple(out.shape) == (2, 21, 32, 32)
+    da10 = PoseResNetx10(bb2, da.upsampling, 256, 21).to(gpu).eval()
+    with torch.no_grad():
+        out10 = da10(x.to(gpu))
+    assert isinstance(out10, tuple) and len(out10) == 5 and tuple(out10[3].shape) == (2, 21, 8, 8) and tuple(out10[4].shape) == (2, 256, 32, 32)
+    lam0 = da.gl_layer.coeff
+    da.step()
+    assert da.gl_layer.iter_num == 1 and da.gl_layer.coeff > lam0 == 0.0
+
+
+def test_batch_of_one_and_frozen_parameters(gpu):
+    """B=1 (BatchNorm over a single image) and requires_grad=False parameters (the frozen EMA copy, train1.py:115-117)."""
+    import uda.model as models
+    from uda.model.pose_resnet2 import Upsampling
+    from uda.model.regda_7 import PoseResNetx10
+    bb = models.resnet18()
+    m = PoseResNetx10(bb, Upsampling(bb.out_features), 256, 21).to(gpu)
+    for p in m.parameters():
+        p.requires_grad = False
+    m.train()
+    x = randn(35, 1, 3, 256, 256).to(gpu)
+    y, y_adv, y_adv2, y_adv3, f = m(x)
+    assert not y.requires_grad and all(p.grad is None for p in m.parameters())   # nothing to differentiate, nothing written
+    assert torch.isfinite(y).all() and tuple(y_adv2.shape) == (1, 21, 32, 32)
+    # un-freeze one head: only its parameters receive gradients, the frozen rest stays untouched
+    for p in m.head_adv3.parameters():
+        p.requires_grad = True
+    y, y_adv, y_adv2, y_adv3, f = m(x)
+    y_adv3.sum().backward()
+    got = {n for n, p in m.named_parameters() if p.grad is not None}
+    assert got and all(n.startswith('head_adv3.') for n in got)
