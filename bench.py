@@ -108,6 +108,7 @@ def cpu_baseline(arch, image_size, batch, iters):
 
 
 def main():
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')     # dmabuf IPC for RCCL; must be set before HIP initialises
     args = parse()
     rank = int(os.environ.get('RANK', 0))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
