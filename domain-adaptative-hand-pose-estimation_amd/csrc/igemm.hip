@@ -11,21 +11,24 @@
 #define MAX_TAPS 52
 struct Tap { int8_t dy, dx; int16_t widx; };
 
+// One launch covers up to 4 independent sub-problems ("phases") that share A, B, D and the tile shape: the stride^2
+// output phases of a strided dgrad / ConvTranspose forward, each a unit-stride gather over its own tap subset.
+// Logical tile id = tile_in_phase * nphase + phase, so every XCD gets the same mix of light and heavy phases.
+struct Phase { int OHp, OWp, out_oy, out_ox, M, ntaps, tap0, ntm; };
 struct GatherArgs {
   const void* A; const void* B; void* D;
   const float* bias; const void* residual; const float* scale;
   int Hi, Wi, Ci;
-  int OHp, OWp;
   int in_sy, in_sx;
   int Ho, Wo;
-  int out_sy, out_sx, out_oy, out_ox;
+  int out_sy, out_sx;
   int Nout, ldb, ldd;
-  int ntaps, cshift, kchunks;
-  int M;
+  int cshift;
   int accumulate;
-  int ntm, ntn;
+  int nphase, ntn, ntiles;     // ntiles = nphase * max_phase(ntm) * ntn
   int hw;                      // heat-map output mode: pixels per image
   unsigned a_bytes, b_bytes;
+  Phase ph[4];
   Tap taps[MAX_TAPS];
 };
 
@@ -80,8 +83,12 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gather_gemm_kernel(const Gathe
   int* row_off = reinterpret_cast<int*>(smem + SM::kBytes - BM * 4);
 
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  const int nblk = p.ntm * p.ntn;
-  const int tile = xcd_remap(blockIdx.x, nblk);
+  const int tile_g = xcd_remap(blockIdx.x, p.ntiles);
+  const int phi = tile_g % p.nphase, tile = tile_g / p.nphase;
+  const Phase& P = p.ph[phi];
+  if (tile >= P.ntm * p.ntn) return;                 // phases of unequal size (odd extents): block-uniform exit
+  const int pM = P.M, pOHp = P.OHp, pOWp = P.OWp, pkchunks = P.ntaps << p.cshift;
+  const Tap* __restrict__ ptaps = p.taps + P.tap0;
   const int m0 = (tile / p.ntn) * BM, n0 = (tile % p.ntn) * BN;
   const int wm0 = (wave / WGN) * WM, wn0 = (wave % WGN) * WN;
   const int lc = t & 7, lr = t >> 3;
@@ -93,16 +100,16 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gather_gemm_kernel(const Gathe
 #pragma unroll
   for (int i = 0; i < RA; ++i) {
     int m = m0 + lr + RPP * i;
-    if (m < p.M) {
-      int ox = m % p.OWp, r = m / p.OWp, oy = r % p.OHp, n = r / p.OHp;
+    if (m < pM) {
+      int ox = m % pOWp, r = m / pOWp, oy = r % pOHp, n = r / pOHp;
       iy0[i] = oy * p.in_sy; ix0[i] = ox * p.in_sx; abase[i] = n * p.Hi * p.Wi;
     } else { iy0[i] = -(1 << 20); ix0[i] = 0; abase[i] = 0; }
   }
   if (t < BM) {  // output pixel offset (elements) of every tile row, -1 when out of range
     int m = m0 + t, off = -1;
-    if (m < p.M) {
-      int ox = m % p.OWp, r = m / p.OWp, oy = r % p.OHp, n = r / p.OHp;
-      off = ((n * p.Ho + oy * p.out_sy + p.out_oy) * p.Wo + ox * p.out_sx + p.out_ox) * p.ldd;
+    if (m < pM) {
+      int ox = m % pOWp, r = m / pOWp, oy = r % pOHp, n = r / pOHp;
+      off = ((n * p.Ho + oy * p.out_sy + P.out_oy) * p.Wo + ox * p.out_sx + P.out_ox) * p.ldd;
     }
     row_off[t] = off;
   }
@@ -115,9 +122,9 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gather_gemm_kernel(const Gathe
   const int cmask = (1 << p.cshift) - 1;
   auto load_tile = [&](int kt, uint4 (&ra)[RA], uint4 (&rb)[RB]) {
     int q, tap, cc; bool okq;
-    if (SMALL_C) { q = kt * 8 + lc; okq = q < p.kchunks; tap = okq ? (q >> p.cshift) : 0; cc = (q & cmask) * CH; }
+    if (SMALL_C) { q = kt * 8 + lc; okq = q < pkchunks; tap = okq ? (q >> p.cshift) : 0; cc = (q & cmask) * CH; }
     else { int q0 = kt * 8; tap = q0 >> p.cshift; cc = ((q0 & cmask) + lc) * CH; okq = true; }
-    const Tap tp = p.taps[tap];
+    const Tap tp = ptaps[tap];
     const int koff = (int)tp.widx * p.Ci + cc;
 #pragma unroll
     for (int i = 0; i < RA; ++i) {
@@ -138,7 +145,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gather_gemm_kernel(const Gathe
   auto dma_tile = [&](int kt, int stage) {
     const int q0 = kt * 8, tap = q0 >> p.cshift;
     const int cc = ((q0 & cmask) + lcs) * CH;
-    const Tap tp = p.taps[tap];
+    const Tap tp = ptaps[tap];
     const int koff = (int)tp.widx * p.Ci + cc;
 #if defined(__HIP_DEVICE_COMPILE__)    // (the host pass must still be able to emit the kernel stub)
     typedef __attribute__((address_space(3))) void* ldsp;
@@ -209,7 +216,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gather_gemm_kernel(const Gathe
     }
   };
 
-  const int nk = (p.kchunks + 7) >> 3;
+  const int nk = (pkchunks + 7) >> 3;
   if constexpr (DMA) {
     dma_tile(0, 0);
     for (int kt = 0; kt < nk; ++kt) {
@@ -327,7 +334,7 @@ struct WgradArgs {
 __device__ __forceinline__ int swz256(int r, int ch) { return r * 256 + ((ch ^ (((r & 3) << 2) | ((r >> 2) & 3))) << 4); }
 
 template <typename T>
-__global__ __launch_bounds__(256) void wgrad_gemm_kernel(const WgradArgs p) {
+__global__ __launch_bounds__(256, 3) void wgrad_gemm_kernel(const WgradArgs p) {
   constexpr int CH = MmaTraits<T>::CH;
   constexpr int BKM = (sizeof(T) == 2) ? 64 : 32;   // reduction rows per LDS tile
   constexpr int CPR = 128 / CH;                      // chunks per 128-wide tile row
@@ -479,6 +486,166 @@ __global__ __launch_bounds__(256) void wgrad_gemm_kernel(const WgradArgs p) {
       }
 }
 
+// ------------------------------------------------------------------------------------ wgrad, 3x3 stride 1 (bf16)
+// The three horizontal taps of one kernel row share ONE staged X tile: with unit stride the tap (kh, kw) operand of
+// output pixel m is the input pixel m + (kh-1)*W + (kw-1), i.e. the kw taps are the same rows shifted by -1 / 0 / +1.
+// A block owns (128|64 output channels) x (64 input channels) x (kh; kw = 0,1,2): per 64-pixel step it stages one DY
+// tile and one X tile (the X tile once instead of three times) and issues 3x the MFMAs of the generic kernel's step.
+// Row shifts must not leak across image rows: the LDS X image keeps every run of min(W,64) pixels in its own segment
+// with 4 spare rows between segments (the row before / after a segment is the halo: zero at the image border, the
+// neighbouring pixel when W > 64), so a shifted tr16 read picks up zeros exactly where the padding is.
+struct WgradKwArgs {
+  const void* X; const void* DY; float* out;
+  int H, W, Ci, Co;
+  int lw, lwf, halo;            // log2(min(W,64)), log2(W), W > 64
+  int M, rows_per_split, ldw;
+  long slab_stride;
+  int nto, nci;
+  unsigned x_bytes, dy_bytes;
+  FastDiv dH;
+};
+// 128-byte rows, tr16-read friendly for any 4 consecutive rows (shifted reads included)
+__device__ __forceinline__ int swzx(int r, int ch) { return r * 128 + ((ch ^ (((r >> 1) & 1) << 2)) << 4); }
+
+template <int MT>
+__global__ __launch_bounds__(256, 3) void wgrad_kw_kernel(const WgradKwArgs p) {
+  constexpr int BO = 64 * MT, BKM = 64;
+  constexpr int CPRY = BO / 8, RPY = 256 / CPRY, NPY = BKM / RPY;
+  constexpr int XROWS = 64 + 4 * 8 + 4;
+  __shared__ __attribute__((aligned(16))) char smem[BKM * 256 + XROWS * 128 + 2 * BKM * 4];
+  char* ys = smem;
+  char* xs = smem + BKM * 256;
+  int* rowinfo = reinterpret_cast<int*>(smem + BKM * 256 + XROWS * 128);   // [2][BKM]: image row oy of each pixel
+
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int ntile = p.nto * 3 * p.nci;
+  const int lid = xcd_remap(blockIdx.x, gridDim.x);
+  const int split = lid / ntile;
+  int tile = lid - split * ntile;
+  const int ot = tile / (3 * p.nci); tile -= ot * 3 * p.nci;
+  const int kh = tile / p.nci, cit = tile - kh * p.nci;
+  const int o0 = ot * BO, ci0 = cit * 64, tdy = kh - 1;
+  const int wm0 = (wave >> 1) * (32 * MT), wn0 = (wave & 1) * 32;
+
+  const __amdgpu_buffer_rsrc_t rsX = make_rsrc(p.X, p.x_bytes), rsY = make_rsrc(p.DY, p.dy_bytes);
+  const int lcy = t % CPRY, lry = t / CPRY;
+  const int lcx = t & 7, lrx = t >> 3;
+  const bool ook = (o0 + lcy * 8) < p.Co;
+  const bool cok = (ci0 + lcx * 8) < p.Ci;
+  const int mbeg = split * p.rows_per_split;
+  const int mend = min(p.M, mbeg + p.rows_per_split);
+
+  for (int i = t; i < XROWS * 8; i += 256) reinterpret_cast<uint4*>(xs)[i] = make_uint4(0, 0, 0, 0);
+
+  uint4 ry[NPY], rx[2], rh = make_uint4(0, 0, 0, 0);
+  auto decode_rows = [&](int mt0, int buf) {
+    if (t < BKM) {
+      const unsigned m = (unsigned)(mt0 + t);
+      const unsigned r = m >> p.lwf;
+      const unsigned n = fd_div(r, p.dH);
+      rowinfo[buf * BKM + t] = (m < (unsigned)p.M) ? (int)(r - n * p.H) : -(1 << 20);
+    }
+  };
+  auto load_tile = [&](int mt0, int buf) {
+#pragma unroll
+    for (int i = 0; i < NPY; ++i) {
+      const int m = mt0 + lry + RPY * i;
+      ry[i] = buf_load16(rsY, (m < mend && ook) ? (m * p.Co + o0 + lcy * 8) * 2 : OOB_OFF);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int rr = lrx + 32 * i, m = mt0 + rr;
+      const int oy = rowinfo[buf * BKM + rr];
+      const bool ok = cok && (unsigned)(oy + tdy) < (unsigned)p.H;
+      rx[i] = buf_load16(rsX, ok ? ((m + tdy * p.W) * p.Ci + ci0 + lcx * 8) * 2 : OOB_OFF);
+    }
+    if (p.halo && t < 16) {     // W > 64: the tile is a 64-pixel piece of one image row; fetch its two neighbours
+      const int side = t >> 3, ox0 = mt0 & (p.W - 1);
+      const int oy = rowinfo[buf * BKM];
+      const bool ok = (side ? (ox0 + 64 < p.W) : (ox0 > 0)) && (unsigned)(oy + tdy) < (unsigned)p.H && (ci0 + (t & 7) * 8) < p.Ci;
+      const int m = mt0 + (side ? 64 : -1);
+      rh = buf_load16(rsX, ok ? ((m + tdy * p.W) * p.Ci + ci0 + (t & 7) * 8) * 2 : OOB_OFF);
+    }
+  };
+  auto store_tile = [&]() {
+#pragma unroll
+    for (int i = 0; i < NPY; ++i) *reinterpret_cast<uint4*>(ys + swz256(lry + RPY * i, lcy)) = ry[i];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int r = lrx + 32 * i;
+      *reinterpret_cast<uint4*>(xs + swzx(r + 2 + 4 * (r >> p.lw), lcx)) = rx[i];
+    }
+    if (p.halo && t < 16) *reinterpret_cast<uint4*>(xs + swzx((t >> 3) ? 66 : 1, t & 7)) = rh;
+  };
+
+  f32x16_t acc[3][MT];
+#pragma unroll
+  for (int a = 0; a < 3; ++a)
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][i][r] = 0.f;
+
+  const int r31 = lane & 31, hi = lane >> 5;
+  const int tg = lane >> 4, tq = (lane & 15) >> 2, tp = lane & 3;
+  int trA[MT][2], trB[3][2];
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int row = 8 * (tg >> 1) + tq + 4 * u;                 // reduction row inside a 16-row k-step
+#pragma unroll
+    for (int i = 0; i < MT; ++i) trA[i][u] = swz256(row, (wm0 + i * 32) / 8 + 2 * (tg & 1) + (tp >> 1)) + 8 * (tp & 1);
+    const int R0 = row + 2 + 4 * (row >> p.lw);
+#pragma unroll
+    for (int a = 0; a < 3; ++a) trB[a][u] = swzx(R0 + a - 1, wn0 / 8 + 2 * (tg & 1) + (tp >> 1)) + 8 * (tp & 1);
+  }
+  decode_rows(mbeg, 0);
+  __syncthreads();
+  if (mbeg < mend) load_tile(mbeg, 0);
+  int buf = 0;
+  for (int mt0 = mbeg; mt0 < mend; mt0 += BKM, buf ^= 1) {
+    __syncthreads();
+    store_tile();
+    decode_rows(mt0 + BKM, buf ^ 1);
+    __syncthreads();
+    if (mt0 + BKM < mend) load_tile(mt0 + BKM, buf ^ 1);
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      typedef __attribute__((address_space(3))) bf16x4_t* lds4;
+      const int eoff = (16 * s + 4 * ((16 * s) >> p.lw)) * 128;       // image-row offset of k-step s (uniform)
+      bf16x8_t a[MT], b[3];
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+        bf16x4_t a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4)(ys + trA[i][0] + s * 4096));
+        bf16x4_t a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4)(ys + trA[i][1] + s * 4096));
+        a[i] = __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7);
+      }
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        bf16x4_t b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4)(xs + trB[k][0] + eoff));
+        bf16x4_t b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4)(xs + trB[k][1] + eoff));
+        b[k] = __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7);
+      }
+#pragma unroll
+      for (int k = 0; k < 3; ++k)
+#pragma unroll
+        for (int i = 0; i < MT; ++i) acc[k][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[k], acc[k][i], 0, 0, 0);
+    }
+    __builtin_amdgcn_s_setprio(0);
+  }
+  float* out = p.out + (size_t)split * p.slab_stride;
+#pragma unroll
+  for (int k = 0; k < 3; ++k)
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int o = o0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+        const int c = ci0 + wn0 + r31;
+        if (o < p.Co && c < p.Ci) out[(size_t)o * p.ldw + (kh * 3 + k) * p.Ci + c] = acc[k][i][r];
+      }
+}
+
 __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ out, long n, int S,
                                                            long stride, int accumulate) {
   // float4 per lane, 4 slabs in flight per step; fixed summation order (s = 0, 1, 2, ...)
@@ -508,12 +675,15 @@ static int ilog2_exact(int v) { int s = 0; while ((1 << s) < v) ++s; return ((1 
 
 template <typename T, int BM, int BN, bool SMALL_C, int WGM = 2, int WGN = 2, bool HM_OUT = false, bool DMA = false>
 static void launch_gather(GatherArgs& a, hipStream_t st) {
-  a.ntm = cdiv(a.M, BM); a.ntn = cdiv(a.Nout, BN);
+  a.ntn = cdiv(a.Nout, BN);
+  int mx = 0;
+  for (int i = 0; i < a.nphase; ++i) { a.ph[i].ntm = cdiv(a.ph[i].M, BM); if (a.ph[i].ntm > mx) mx = a.ph[i].ntm; }
+  a.ntiles = a.nphase * mx * a.ntn;
   constexpr int smem = GatherSmem<T, BM, BN, DMA ? 2 : 1>::kBytes;
   auto kern = gather_gemm_kernel<T, BM, BN, SMALL_C, WGM, WGN, HM_OUT, DMA>;
   static bool attr_set = false;   // raise the dynamic-LDS cap once per instantiation
   if (!attr_set) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem); attr_set = true; }
-  hipLaunchKernelGGL(kern, dim3(a.ntm * a.ntn), dim3(64 * WGM * WGN), smem, st, a);
+  hipLaunchKernelGGL(kern, dim3(a.ntiles), dim3(64 * WGM * WGN), smem, st, a);
 }
 
 template <typename T>
@@ -523,17 +693,22 @@ static int dispatch_gather(GatherArgs& a, hipStream_t st) {
   a.cshift = ilog2_exact(a.Ci / CH);
   if (a.cshift < 0) MI_FAIL(MI355_EINVAL, "gather: Ci/%d must be a power of two (Ci=%d)", CH, a.Ci);
   if (a.Nout % CH) MI_FAIL(MI355_EINVAL, "gather: Nout=%d not a multiple of %d", a.Nout, CH);
-  a.kchunks = a.ntaps << a.cshift;
+  if (a.nphase < 1 || a.nphase > 4) MI_FAIL(MI355_EINVAL, "gather: nphase=%d", a.nphase);
+  long Mtot = 0, ntaps_tot = 0; int kchunks = 0; double flops = 0.0;
+  for (int i = 0; i < a.nphase; ++i) {
+    Mtot += a.ph[i].M; ntaps_tot += a.ph[i].ntaps;
+    if ((a.ph[i].ntaps << a.cshift) > kchunks) kchunks = a.ph[i].ntaps << a.cshift;
+    flops += 2.0 * a.ph[i].M * (double)a.Nout * a.ph[i].ntaps * a.Ci;
+  }
   {
     // A spans [images][Hi][Wi][Ci]; images = M / (OHp*OWp)
-    const long imgs = a.M / ((long)a.OHp * a.OWp);
+    const long imgs = a.ph[0].M / ((long)a.ph[0].OHp * a.ph[0].OWp);
     a.a_bytes = (unsigned)(imgs * a.Hi * a.Wi * a.Ci * (long)sizeof(T));
     a.b_bytes = (unsigned)((long)a.Nout * a.ldb * (long)sizeof(T));
   }
   const bool small = (a.Ci / CH) < 8;
-  double flops = 2.0 * a.M * (double)a.Nout * a.ntaps * a.Ci;
   // algorithmic bytes: every input element, weight and output element once
-  ProfScope ps(st, flops, (double)a.a_bytes + (double)a.b_bytes * a.ntaps / (a.ldb / a.Ci) + (double)a.M * a.Nout * sizeof(T));
+  ProfScope ps(st, flops, (double)a.a_bytes + (double)a.b_bytes * ntaps_tot / (a.ldb / a.Ci) + (double)Mtot * a.Nout * sizeof(T));
   static const int force = getenv("MI355_TILE") ? atoi(getenv("MI355_TILE")) : -1;   // experiment switch
   static const int dma_mode = getenv("MI355_DMA") ? atoi(getenv("MI355_DMA")) : 1;
   if (small) { launch_gather<T, 128, 64, true>(a, st); }
@@ -542,15 +717,15 @@ static int dispatch_gather(GatherArgs& a, hipStream_t st) {
   else if (force == 2) launch_gather<T, 128, 64, false>(a, st);
   else if (force == 3) launch_gather<T, 64, 64, false>(a, st);
   else {
-    const long t128 = (long)cdiv(a.M, 128) * cdiv(a.Nout, 128);
+    const long t128 = cdiv(Mtot, 128L) * cdiv(a.Nout, 128);
     if (a.Nout <= 64) {
-      if ((long)cdiv(a.M, 128) >= 512) launch_gather<T, 128, 64, false>(a, st); else launch_gather<T, 64, 64, false>(a, st);
-    } else if (sizeof(T) == 2 && getenv("MI355_T256") && a.Nout % 256 == 0 && (long)cdiv(a.M, 256) * (a.Nout / 256) >= 256) launch_gather<T, 256, 256, false, 2, 4>(a, st);
+      if (cdiv(Mtot, 128L) >= 512) launch_gather<T, 128, 64, false>(a, st); else launch_gather<T, 64, 64, false>(a, st);
+    } else if (sizeof(T) == 2 && getenv("MI355_T256") && a.Nout % 256 == 0 && cdiv(Mtot, 256L) * (a.Nout / 256) >= 256) launch_gather<T, 256, 256, false, 2, 4>(a, st);
     // LDS-DMA ring for K-heavy layers (>= 16 K-tiles): +9..12 % on the 3x3 / 4x4 convs, but -15 % on short-K 1x1 convs
     // (2 blocks/CU instead of 3), so those keep the register-staged form.  MI355_DMA=0 disables, =2 forces (tests).
-    else if ((dma_mode == 2 && a.Nout > 64) || (dma_mode == 1 && t128 >= 512 && a.kchunks >= 128)) launch_gather<T, 128, 128, false, 2, 2, false, true>(a, st);
+    else if ((dma_mode == 2 && a.Nout > 64) || (dma_mode == 1 && t128 >= 512 && kchunks >= 128)) launch_gather<T, 128, 128, false, 2, 2, false, true>(a, st);
     else if (t128 >= 512) launch_gather<T, 128, 128, false>(a, st);   // (128x256 tile with 8 waves measured slower: 687 vs 755 TFLOP/s)
-    else if ((long)cdiv(a.M, 64) * cdiv(a.Nout, 128) >= 512) launch_gather<T, 64, 128, false>(a, st);
+    else if (cdiv(Mtot, 64L) * cdiv(a.Nout, 128) >= 512) launch_gather<T, 64, 128, false>(a, st);
     else launch_gather<T, 64, 64, false>(a, st);
   }
   MI_CHECK_LAUNCH("gather_gemm");
@@ -574,10 +749,10 @@ extern "C" int mi355_conv_fwd(const mi355_conv_desc* d, const void* x, const voi
   if (int e = check_desc(d)) return e;
   GatherArgs a; memset(&a, 0, sizeof(a));
   a.A = x; a.B = w; a.D = y; a.bias = bias; a.residual = residual; a.scale = nullptr;
-  a.Hi = d->Hi; a.Wi = d->Wi; a.Ci = d->Ci; a.OHp = d->Ho; a.OWp = d->Wo; a.in_sy = a.in_sx = d->stride;
-  a.Ho = d->Ho; a.Wo = d->Wo; a.out_sy = a.out_sx = 1; a.out_oy = a.out_ox = 0;
-  a.Nout = d->Co; a.ldd = d->Co; a.ldb = d->kh * d->kw * d->Ci; a.M = d->N * d->Ho * d->Wo; a.accumulate = 0;
-  a.ntaps = d->kh * d->kw;
+  a.Hi = d->Hi; a.Wi = d->Wi; a.Ci = d->Ci; a.in_sy = a.in_sx = d->stride;
+  a.Ho = d->Ho; a.Wo = d->Wo; a.out_sy = a.out_sx = 1;
+  a.Nout = d->Co; a.ldd = d->Co; a.ldb = d->kh * d->kw * d->Ci; a.accumulate = 0;
+  a.nphase = 1; a.ph[0].OHp = d->Ho; a.ph[0].OWp = d->Wo; a.ph[0].M = d->N * d->Ho * d->Wo; a.ph[0].ntaps = d->kh * d->kw;
   for (int i = 0; i < d->kh; ++i)
     for (int j = 0; j < d->kw; ++j) { Tap& t = a.taps[i * d->kw + j]; t.dy = (int8_t)(i - d->pad); t.dx = (int8_t)(j - d->pad); t.widx = (int16_t)(i * d->kw + j); }
   return d->dtype == MI355_BF16 ? dispatch_gather<bf16_t>(a, as_stream(stream)) : dispatch_gather<float>(a, as_stream(stream));
@@ -589,16 +764,16 @@ static int heatmap_conv(const void* x, const void* w, const float* bias, float* 
   constexpr int CH = MmaTraits<T>::CH;
   GatherArgs a; memset(&a, 0, sizeof(a));
   a.A = x; a.B = w; a.D = y; a.bias = bias;
-  a.Hi = 1; a.Wi = HW; a.Ci = C; a.OHp = 1; a.OWp = HW; a.in_sy = a.in_sx = 1;
+  a.Hi = 1; a.Wi = HW; a.Ci = C; a.in_sy = a.in_sx = 1;
   a.Ho = 1; a.Wo = HW; a.out_sy = a.out_sx = 1; a.ldd = 1; a.hw = HW;
-  a.Nout = K; a.ldb = C; a.M = N * HW; a.ntaps = 1;
+  a.Nout = K; a.ldb = C;
+  a.nphase = 1; a.ph[0].OHp = 1; a.ph[0].OWp = HW; a.ph[0].M = N * HW; a.ph[0].ntaps = 1;
   if (C % CH) MI_FAIL(MI355_EINVAL, "conv1x1_heatmap: C=%d not a multiple of %d", C, CH);
   a.cshift = ilog2_exact(C / CH);
   if (a.cshift < 3) MI_FAIL(MI355_EINVAL, "conv1x1_heatmap: C/%d must be a power of two >= 8 (C=%d)", CH, C);
-  a.kchunks = 1 << a.cshift;
   a.a_bytes = (unsigned)((long)N * HW * C * (long)sizeof(T));
   a.b_bytes = (unsigned)((long)K * C * (long)sizeof(T));
-  ProfScope ps(st, 2.0 * a.M * (double)K * C, (double)a.a_bytes + a.b_bytes + 4.0 * a.M * K);
+  ProfScope ps(st, 2.0 * N * HW * (double)K * C, (double)a.a_bytes + a.b_bytes + 4.0 * N * HW * K);
   launch_gather<T, 128, 32, false, 4, 1, true>(a, st);
   MI_CHECK_LAUNCH("conv1x1_heatmap");
   return MI355_OK;
@@ -635,17 +810,19 @@ extern "C" int mi355_conv_dgrad(const mi355_conv_desc* d, const void* dy, const 
     hipLaunchKernelGGL(zero_fill_kernel, dim3(grid), dim3(256), 0, st, reinterpret_cast<uint4*>(dx), n16);
     MI_CHECK_LAUNCH("zero_fill");
   }
+  GatherArgs a; memset(&a, 0, sizeof(a));
+  a.A = dy; a.B = wT; a.D = dx; a.bias = bias; a.residual = nullptr; a.scale = scale_dev;
+  a.Hi = d->Ho; a.Wi = d->Wo; a.Ci = d->Co;
+  a.in_sy = a.in_sx = 1; a.Ho = d->Hi; a.Wo = d->Wi; a.out_sy = a.out_sx = s;
+  a.Nout = d->Ci; a.ldd = d->Ci; a.ldb = d->kh * d->kw * d->Co;
+  a.accumulate = accumulate ? 1 : 0;
+  int nt = 0;
   for (int py = 0; py < s; ++py)
     for (int px = 0; px < s; ++px) {
-      GatherArgs a; memset(&a, 0, sizeof(a));
-      a.A = dy; a.B = wT; a.D = dx; a.bias = bias; a.residual = nullptr; a.scale = scale_dev;
-      a.Hi = d->Ho; a.Wi = d->Wo; a.Ci = d->Co;
-      a.OHp = (d->Hi - py + s - 1) / s; a.OWp = (d->Wi - px + s - 1) / s;
-      if (a.OHp <= 0 || a.OWp <= 0) continue;
-      a.in_sy = a.in_sx = 1; a.Ho = d->Hi; a.Wo = d->Wi; a.out_sy = a.out_sx = s; a.out_oy = py; a.out_ox = px;
-      a.Nout = d->Ci; a.ldd = d->Ci; a.ldb = d->kh * d->kw * d->Co; a.M = d->N * a.OHp * a.OWp;
-      a.accumulate = accumulate ? 1 : 0;
-      int nt = 0;
+      Phase& P = a.ph[a.nphase];
+      P.OHp = (d->Hi - py + s - 1) / s; P.OWp = (d->Wi - px + s - 1) / s;
+      if (P.OHp <= 0 || P.OWp <= 0) continue;
+      P.out_oy = py; P.out_ox = px; P.M = d->N * P.OHp * P.OWp; P.tap0 = nt;
       for (int kh = 0; kh < d->kh; ++kh) {
         if ((py + d->pad - kh) % s != 0) continue;
         for (int kw = 0; kw < d->kw; ++kw) {
@@ -654,22 +831,39 @@ extern "C" int mi355_conv_dgrad(const mi355_conv_desc* d, const void* dy, const 
           t.widx = (int16_t)(kh * d->kw + kw);
         }
       }
-      if (nt == 0) continue;   // region already zeroed (or left untouched when accumulating)
-      a.ntaps = nt;
-      int e = d->dtype == MI355_BF16 ? dispatch_gather<bf16_t>(a, st) : dispatch_gather<float>(a, st);
-      if (e) return e;
+      P.ntaps = nt - P.tap0;
+      if (P.ntaps == 0) continue;   // region already zeroed (or left untouched when accumulating)
+      ++a.nphase;
     }
+  if (a.nphase == 0) return MI355_OK;
+  static const int merge = getenv("MI355_PHASES") ? atoi(getenv("MI355_PHASES")) : 1;   // 0: one launch per phase (A/B)
+  if (merge || a.nphase == 1)
+    return d->dtype == MI355_BF16 ? dispatch_gather<bf16_t>(a, st) : dispatch_gather<float>(a, st);
+  const int np = a.nphase;
+  for (int i = 0; i < np; ++i) {
+    GatherArgs b = a; b.nphase = 1; b.ph[0] = a.ph[i];
+    int e = d->dtype == MI355_BF16 ? dispatch_gather<bf16_t>(b, st) : dispatch_gather<float>(b, st);
+    if (e) return e;
+  }
   return MI355_OK;
 }
 
-struct WgradPlan { int S, rows_per_split, nto, nti, ldw; };
+struct WgradPlan { int S, rows_per_split, nto, nti, ldw, kw3, mt; };
+static int ilog2_exact(int v);
+static const int g_wgrad_blocks = getenv("MI355_WG_BLOCKS") ? atoi(getenv("MI355_WG_BLOCKS")) : 768;
 static WgradPlan plan_wgrad(const mi355_conv_desc* d) {
   WgradPlan w; w.ldw = d->kh * d->kw * d->Ci;
-  w.nto = cdiv(d->Co, 128); w.nti = cdiv(w.ldw, 128);
   const int bkm = d->dtype == MI355_BF16 ? 64 : 32;
   const long M = (long)d->N * d->Ho * d->Wo;
-  long tiles = (long)w.nto * w.nti;
-  long S = (768 + tiles - 1) / tiles;
+  // 3x3 / stride 1 / pad 1 in bf16 with a power-of-two width: the kw-shared kernel (see wgrad_kw_kernel)
+  static const int kw3_on = getenv("MI355_WGRAD_KW") ? atoi(getenv("MI355_WGRAD_KW")) : 1;
+  w.kw3 = kw3_on && d->dtype == MI355_BF16 && d->kh == 3 && d->kw == 3 && d->stride == 1 && d->pad == 1 &&
+          d->Wi >= 8 && ilog2_exact(d->Wi) >= 0;
+  w.mt = d->Co <= 64 ? 1 : 2;
+  long tiles;
+  if (w.kw3) { w.nto = cdiv(d->Co, 64 * w.mt); w.nti = cdiv(d->Ci, 64); tiles = (long)w.nto * 3 * w.nti; }
+  else { w.nto = cdiv(d->Co, 128); w.nti = cdiv(w.ldw, 128); tiles = (long)w.nto * w.nti; }
+  long S = (g_wgrad_blocks + tiles - 1) / tiles;
   long maxS = (M + 4 * bkm - 1) / (4 * bkm);
   if (S > maxS) S = maxS;
   if (S < 1) S = 1;
@@ -696,6 +890,29 @@ extern "C" int mi355_conv_wgrad(const mi355_conv_desc* d, const void* x, const v
   const size_t need = (size_t)w.S * d->Co * w.ldw * sizeof(float);
   const bool direct = (w.S == 1 && !accumulate);
   if (!direct && (ws == nullptr || ws_bytes < need)) MI_FAIL(MI355_EWORKSPACE, "wgrad workspace %zu < %zu", ws_bytes, need);
+  if (w.kw3) {
+    WgradKwArgs k; memset(&k, 0, sizeof(k));
+    k.X = x; k.DY = dy; k.out = direct ? dw : reinterpret_cast<float*>(ws);
+    k.H = d->Hi; k.W = d->Wi; k.Ci = d->Ci; k.Co = d->Co;
+    k.lwf = ilog2_exact(d->Wi); k.lw = k.lwf > 6 ? 6 : k.lwf; k.halo = d->Wi > 64;
+    k.M = d->N * d->Ho * d->Wo; k.rows_per_split = w.rows_per_split; k.ldw = w.ldw;
+    k.slab_stride = (long)d->Co * w.ldw; k.nto = w.nto; k.nci = w.nti;
+    k.x_bytes = (unsigned)((long)d->N * d->Hi * d->Wi * d->Ci * 2); k.dy_bytes = (unsigned)((long)k.M * d->Co * 2);
+    k.dH = make_fastdiv(d->Hi);
+    {
+      ProfScope ps(st, 2.0 * k.M * (double)d->Co * w.ldw, (double)k.x_bytes + (double)k.dy_bytes + 4.0 * d->Co * w.ldw);
+      dim3 grid(w.nto * 3 * w.nti * w.S);
+      if (w.mt == 1) hipLaunchKernelGGL(wgrad_kw_kernel<1>, grid, dim3(256), 0, st, k);
+      else hipLaunchKernelGGL(wgrad_kw_kernel<2>, grid, dim3(256), 0, st, k);
+      MI_CHECK_LAUNCH("wgrad_kw");
+    }
+    if (!direct) {
+      long n = k.slab_stride;
+      hipLaunchKernelGGL(slab_reduce_kernel, dim3(cdiv(n / 4, 256)), dim3(256), 0, st, reinterpret_cast<const float*>(ws), dw, n, w.S, k.slab_stride, accumulate);
+      MI_CHECK_LAUNCH("slab_reduce");
+    }
+    return MI355_OK;
+  }
   WgradArgs a; memset(&a, 0, sizeof(a));
   a.X = x; a.DY = dy; a.out = direct ? dw : reinterpret_cast<float*>(ws);
   a.Hi = d->Hi; a.Wi = d->Wi; a.Ci = d->Ci; a.Ho = d->Ho; a.Wo = d->Wo; a.Co = d->Co;

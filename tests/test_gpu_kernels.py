@@ -50,6 +50,11 @@ CONV_CASES = [
     (2, 256, 16, 16, 64, 4, 2, 1),    # conv-form of ConvTranspose2d(64 -> 256, 4, 2, 1)
     (1, 64, 9, 13, 64, 3, 1, 1),      # ragged spatial size (M not a tile multiple)
     (5, 128, 12, 12, 64, 3, 2, 1),    # odd batch, M = 180 rows (partial tiles)
+    # 3x3 / stride 1 with power-of-two widths: the kw-shared wgrad kernel (bf16), one case per LDS segment size
+    (3, 64, 8, 8, 128, 3, 1, 1),      # W = 8: eight image rows per 64-pixel tile, M = 192
+    (1, 128, 32, 32, 256, 3, 1, 1),   # W = 32, two output-channel tiles x two input-channel tiles
+    (1, 64, 20, 64, 128, 3, 1, 1),    # W = 64: one image row per tile, H not a power of two
+    (1, 64, 6, 128, 64, 3, 1, 1),     # W = 128: half rows with halo pixels fetched from the neighbours
 ]
 
 
