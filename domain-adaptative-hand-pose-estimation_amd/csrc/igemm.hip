@@ -646,23 +646,59 @@ __global__ __launch_bounds__(256, 3) void wgrad_kw_kernel(const WgradKwArgs p) {
       }
 }
 
+// Fixed-order slab reduction.  SL "slab lanes" share each float4 column: lane j sums slabs j, j+SL, ... (4 loads in
+// flight), the SL partial sums are then added in lane order -- the order depends only on (S, SL), never on timing.
+template <int SL>
 __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ out, long n, int S,
                                                            long stride, int accumulate) {
-  // float4 per lane, 4 slabs in flight per step; fixed summation order (s = 0, 1, 2, ...)
+  constexpr int COLS = 256 / SL;
+  __shared__ float4 part[SL > 1 ? 256 : 1];
   const long n4 = n >> 2;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
-    float4 v = accumulate ? reinterpret_cast<const float4*>(out)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
-    int s = 0;
-    for (; s + 4 <= S; s += 4) {
-      float4 a[4];
+  const int col = threadIdx.x % COLS, sl = threadIdx.x / COLS;
+  for (long i0 = (long)blockIdx.x * COLS; i0 < n4; i0 += (long)gridDim.x * COLS) {
+    const long i = i0 + col;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (i < n4) {
+      int s = sl;
+      for (; s + 3 * SL < S; s += 4 * SL) {
+        float4 a[4];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) a[u] = reinterpret_cast<const float4*>(slabs + (size_t)(s + u) * stride)[i];
+        for (int u = 0; u < 4; ++u) a[u] = reinterpret_cast<const float4*>(slabs + (size_t)(s + u * SL) * stride)[i];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) { v.x += a[u].x; v.y += a[u].y; v.z += a[u].z; v.w += a[u].w; }
+        for (int u = 0; u < 4; ++u) { v.x += a[u].x; v.y += a[u].y; v.z += a[u].z; v.w += a[u].w; }
+      }
+      for (; s < S; s += SL) { const float4 a = reinterpret_cast<const float4*>(slabs + (size_t)s * stride)[i]; v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w; }
     }
-    for (; s < S; ++s) { const float4 a = reinterpret_cast<const float4*>(slabs + (size_t)s * stride)[i]; v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w; }
-    reinterpret_cast<float4*>(out)[i] = v;
+    if constexpr (SL > 1) {
+      __syncthreads();
+      part[threadIdx.x] = v;
+      __syncthreads();
+      if (sl == 0 && i < n4) {
+        float4 r = accumulate ? reinterpret_cast<const float4*>(out)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int j = 0; j < SL; ++j) { const float4 q = part[j * COLS + col]; r.x += q.x; r.y += q.y; r.z += q.z; r.w += q.w; }
+        reinterpret_cast<float4*>(out)[i] = r;
+      }
+    } else {
+      if (i < n4) {
+        if (accumulate) { const float4 o = reinterpret_cast<const float4*>(out)[i]; v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
+        reinterpret_cast<float4*>(out)[i] = v;
+      }
+    }
   }
+}
+static void launch_slab_reduce(const float* ws, float* dw, long n, int S, long stride, int accumulate, hipStream_t st) {
+  const long n4 = n / 4;
+  // enough slab lanes that ~64K threads stream, but never more lanes than slabs
+  int SL = 1;
+  while (SL < 16 && n4 * SL < 65536 && SL * 2 <= S) SL *= 2;
+  const int cols = 256 / SL;
+  dim3 grid(cdiv(n4, cols));
+  if (SL == 1) hipLaunchKernelGGL(slab_reduce_kernel<1>, grid, dim3(256), 0, st, ws, dw, n, S, stride, accumulate);
+  else if (SL == 2) hipLaunchKernelGGL(slab_reduce_kernel<2>, grid, dim3(256), 0, st, ws, dw, n, S, stride, accumulate);
+  else if (SL == 4) hipLaunchKernelGGL(slab_reduce_kernel<4>, grid, dim3(256), 0, st, ws, dw, n, S, stride, accumulate);
+  else if (SL == 8) hipLaunchKernelGGL(slab_reduce_kernel<8>, grid, dim3(256), 0, st, ws, dw, n, S, stride, accumulate);
+  else hipLaunchKernelGGL(slab_reduce_kernel<16>, grid, dim3(256), 0, st, ws, dw, n, S, stride, accumulate);
 }
 
 // plain zero-fill (own kernel rather than hipMemsetAsync: a kernel node replays identically inside HIP graphs)
@@ -707,6 +743,8 @@ static int dispatch_gather(GatherArgs& a, hipStream_t st) {
     a.b_bytes = (unsigned)((long)a.Nout * a.ldb * (long)sizeof(T));
   }
   const bool small = (a.Ci / CH) < 8;
+  const long kavg = (ntaps_tot << a.cshift) / a.nphase;   // phases of a strided dgrad differ in length
+  (void)kchunks;
   // algorithmic bytes: every input element, weight and output element once
   ProfScope ps(st, flops, (double)a.a_bytes + (double)a.b_bytes * ntaps_tot / (a.ldb / a.Ci) + (double)Mtot * a.Nout * sizeof(T));
   static const int force = getenv("MI355_TILE") ? atoi(getenv("MI355_TILE")) : -1;   // experiment switch
@@ -723,7 +761,7 @@ static int dispatch_gather(GatherArgs& a, hipStream_t st) {
     } else if (sizeof(T) == 2 && getenv("MI355_T256") && a.Nout % 256 == 0 && cdiv(Mtot, 256L) * (a.Nout / 256) >= 256) launch_gather<T, 256, 256, false, 2, 4>(a, st);
     // LDS-DMA ring for K-heavy layers (>= 16 K-tiles): +9..12 % on the 3x3 / 4x4 convs, but -15 % on short-K 1x1 convs
     // (2 blocks/CU instead of 3), so those keep the register-staged form.  MI355_DMA=0 disables, =2 forces (tests).
-    else if ((dma_mode == 2 && a.Nout > 64) || (dma_mode == 1 && t128 >= 512 && kchunks >= 128)) launch_gather<T, 128, 128, false, 2, 2, false, true>(a, st);
+    else if ((dma_mode == 2 && a.Nout > 64) || (dma_mode == 1 && t128 >= 512 && kavg >= 128)) launch_gather<T, 128, 128, false, 2, 2, false, true>(a, st);
     else if (t128 >= 512) launch_gather<T, 128, 128, false>(a, st);   // (128x256 tile with 8 waves measured slower: 687 vs 755 TFLOP/s)
     else if (cdiv(Mtot, 64L) * cdiv(a.Nout, 128) >= 512) launch_gather<T, 64, 128, false>(a, st);
     else launch_gather<T, 64, 64, false>(a, st);
@@ -863,9 +901,16 @@ static WgradPlan plan_wgrad(const mi355_conv_desc* d) {
   long tiles;
   if (w.kw3) { w.nto = cdiv(d->Co, 64 * w.mt); w.nti = cdiv(d->Ci, 64); tiles = (long)w.nto * 3 * w.nti; }
   else { w.nto = cdiv(d->Co, 128); w.nti = cdiv(w.ldw, 128); tiles = (long)w.nto * w.nti; }
+  // split count: fill the chip (3 blocks per CU), but keep >= 16 reduction steps per block while at least one block
+  // per CU remains -- short blocks are all prologue / epilogue and every split costs a full fp32 slab write + read.
+  // (measured per layer, B=64 @256x256: see DESIGN.md)
+  const long ksteps = (M + bkm - 1) / bkm;
   long S = (g_wgrad_blocks + tiles - 1) / tiles;
-  long maxS = (M + 4 * bkm - 1) / (4 * bkm);
-  if (S > maxS) S = maxS;
+  long S16 = ksteps / 16, S256 = (256 + tiles - 1) / tiles;
+  long lo = S16 > S256 ? S16 : S256;
+  if (S > lo) S = lo;
+  if (tiles >= 384) S = 1;                       // enough tiles on their own: direct write, no slab pass
+  if (S > ksteps) S = ksteps;
   if (S < 1) S = 1;
   long rps = (M + S - 1) / S; rps = ((rps + bkm - 1) / bkm) * bkm;
   S = (M + rps - 1) / rps;
@@ -908,7 +953,7 @@ extern "C" int mi355_conv_wgrad(const mi355_conv_desc* d, const void* x, const v
     }
     if (!direct) {
       long n = k.slab_stride;
-      hipLaunchKernelGGL(slab_reduce_kernel, dim3(cdiv(n / 4, 256)), dim3(256), 0, st, reinterpret_cast<const float*>(ws), dw, n, w.S, k.slab_stride, accumulate);
+      launch_slab_reduce(reinterpret_cast<const float*>(ws), dw, n, w.S, k.slab_stride, accumulate, st);
       MI_CHECK_LAUNCH("slab_reduce");
     }
     return MI355_OK;
@@ -930,7 +975,7 @@ extern "C" int mi355_conv_wgrad(const mi355_conv_desc* d, const void* x, const v
   }
   if (!direct) {
     long n = a.slab_stride;
-    hipLaunchKernelGGL(slab_reduce_kernel, dim3(cdiv(n / 4, 256)), dim3(256), 0, st, reinterpret_cast<const float*>(ws), dw, n, w.S, a.slab_stride, accumulate);
+    launch_slab_reduce(reinterpret_cast<const float*>(ws), dw, n, w.S, a.slab_stride, accumulate, st);
     MI_CHECK_LAUNCH("slab_reduce");
   }
   return MI355_OK;
