@@ -90,6 +90,7 @@ def _chk_convform(weight):
 
 # ---------------------------------------------------------------- autograd functions
 import os as _os
+_SKIP_FUSE = _os.environ.get('MI355_SKIP_FUSE', '1') == '1'             # A/B switch: residual-fork gradient add inside dgrad
 _MASK_FROM_Y = _os.environ.get('MI355_BN_MASK_FROM_Y', '0') == '1'     # A/B switch: read y for every ReLU mask
 
 class _ConvFn(torch.autograd.Function):
@@ -118,6 +119,36 @@ class _ConvFn(torch.autograd.Function):
             ops.colsum(dy, g, acc)
         dres = dy if ctx.needs_input_grad[3] else None
         return dx, None, None, dres, None, None
+
+
+class _ConvSkipFn(torch.autograd.Function):
+    """conv(x) together with an alias of x for the parallel branch of a residual block (identity / downsample input).
+    In backward the conv's input gradient is added onto the branch's gradient inside the dgrad epilogue, which replaces
+    the separate element-wise add autograd would run at the fork (one read+write pass of the block input less)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, mod):
+        desc, wf, _ = mod._plan(x)
+        y = ops.conv_fwd(desc, x, wf, None, None)
+        ctx.mod, ctx.desc = mod, desc
+        ctx.save_for_backward(x, weight)
+        return y, x
+
+    @staticmethod
+    def backward(ctx, dy, dskip):
+        x, weight = ctx.saved_tensors
+        mod, desc = ctx.mod, ctx.desc
+        dy = _as_grad(dy, x.dtype)
+        if ctx.needs_input_grad[1]:
+            mod._wgrad(desc, x, dy, weight)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            _, _, wt = mod._plan(x)
+            if dskip is None:
+                dx = ops.conv_dgrad(desc, dy, wt)
+            else:       # dskip is a gradient buffer this library produced (BN / conv backward): accumulate in place
+                dx = ops.conv_dgrad(desc, dy, wt, out=_as_grad(dskip, x.dtype), accumulate=True)
+        return dx, None, None
 
 
 class _DeconvFn(torch.autograd.Function):
@@ -381,6 +412,14 @@ class Conv2d(nn.Module):
         else:
             x = _as_feature(x, dtype)
         return _ConvFn.apply(x, self.weight, self.bias, residual, self, scale)
+
+    def forward_skip(self, x):
+        """(conv(x), alias of x): for residual blocks, see _ConvSkipFn.  Bias-free MFMA convs only."""
+        if not _SKIP_FUSE or self.mode != 'mfma' or self.bias is not None or getattr(x, '_mi_grad_scale', None) is not None or \
+                self.in_channels != self._cin_pad(compute_dtype()):
+            return self.forward(x), x
+        x = _as_feature(x, compute_dtype())
+        return _ConvSkipFn.apply(x, self.weight, self)
 
 
 class ConvTranspose2d(nn.Module):

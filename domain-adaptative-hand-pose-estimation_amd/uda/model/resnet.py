@@ -36,8 +36,9 @@ class BasicBlock(nn.Module):
         self.stride = stride
 
     def forward(self, x):
-        identity = x if self.downsample is None else self.downsample(x)
-        out = self.bn1(self.conv1(x), relu=True)
+        out, skip = self.conv1.forward_skip(x)     # skip aliases x; its gradient is summed inside conv1's dgrad
+        identity = skip if self.downsample is None else self.downsample(skip)
+        out = self.bn1(out, relu=True)
         return self.bn2(self.conv2(out), residual=identity, relu=True)   # BN + add + ReLU in one kernel
 
 
@@ -57,8 +58,9 @@ class Bottleneck(nn.Module):
         self.stride = stride
 
     def forward(self, x):
-        identity = x if self.downsample is None else self.downsample(x)
-        out = self.bn1(self.conv1(x), relu=True)
+        out, skip = self.conv1.forward_skip(x)     # skip aliases x; its gradient is summed inside conv1's dgrad
+        identity = skip if self.downsample is None else self.downsample(skip)
+        out = self.bn1(out, relu=True)
         out = self.bn2(self.conv2(out), relu=True)
         return self.bn3(self.conv3(out), residual=identity, relu=True)
 
