@@ -1,7 +1,8 @@
 // BatchNorm2d over NHWC rows (+ fused ReLU / residual add), train + eval forward and backward,
 // and the bias-gradient column sum.  All of it is HBM-bound: 16-byte vector loads, per-thread
 // channel ownership, Welford/Chan statistics in fp32, slice partials combined in a fixed order
-// (bitwise reproducible; no atomics).
+// (bitwise reproducible; no atomics).  Slice partials stay slice-major: a channel-major layout makes the finalize
+// kernels 35 % faster but the scattered 4-byte partial writes cost the statistics kernels twice that (measured).
 #include "common.h"
 
 struct BnPlan { int cpr, TX, TY, colgroups, nslices, rows_per_slice; };
@@ -92,16 +93,21 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
   const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (blockIdx.x == 0 && threadIdx.x == 0 && nbt) *nbt += repeats;
   if (c >= C) return;                      // wave-uniform
-  float qn[16], qm[16], qv[16];
-#pragma unroll
-  for (int j = 0; j < 16; ++j) {
-    const int s = lane + 64 * j;
-    if (s < nslices) { const float* q = partial + ((size_t)s * C + c) * 3; qn[j] = q[0]; qm[j] = q[1]; qv[j] = q[2]; }
-    else { qn[j] = 0.f; qm[j] = 0.f; qv[j] = 0.f; }
-  }
+  // per-channel scalars first: their latency overlaps the partial loads instead of trailing the fold
+  const float g = gamma[c], b = beta[c];
+  float rm = running_mean ? running_mean[c] : 0.f, rv = running_var ? running_var[c] : 0.f;
   float n = 0.f, mean = 0.f, m2 = 0.f;
+  for (int base = 0; base < nslices; base += 1024) {     // (conv-fused statistics can bring more than 1024 slices)
+    float qn[16], qm[16], qv[16];
 #pragma unroll
-  for (int j = 0; j < 16; ++j) chan_combine(n, mean, m2, qn[j], qm[j], qv[j]);
+    for (int j = 0; j < 16; ++j) {
+      const int s = base + lane + 64 * j;
+      if (s < nslices) { const float* q = partial + ((size_t)s * C + c) * 3; qn[j] = q[0]; qm[j] = q[1]; qv[j] = q[2]; }
+      else { qn[j] = 0.f; qm[j] = 0.f; qv[j] = 0.f; }
+    }
+#pragma unroll
+    for (int j = 0; j < 16; ++j) chan_combine(n, mean, m2, qn[j], qm[j], qv[j]);
+  }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
     const float nb = __shfl_down(n, o, 64), mb = __shfl_down(mean, o, 64), vb = __shfl_down(m2, o, 64);
@@ -114,11 +120,13 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
   // `repeats` identical forward passes over the same batch (training step B -> C reuse) = that many momentum updates
   const float uvar = n > 1.f ? m2 / (n - 1.f) : var;
   for (int r = 0; r < repeats; ++r) {
-    if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
-    if (running_var) running_var[c] = (1.f - momentum) * running_var[c] + momentum * uvar;
+    rm = (1.f - momentum) * rm + momentum * mean;
+    rv = (1.f - momentum) * rv + momentum * uvar;
   }
-  const float sc = gamma[c] * invstd;
-  scale_shift[c] = sc; scale_shift[C + c] = beta[c] - mean * sc;
+  if (running_mean && repeats > 0) running_mean[c] = rm;
+  if (running_var && repeats > 0) running_var[c] = rv;
+  const float sc = g * invstd;
+  scale_shift[c] = sc; scale_shift[C + c] = b - mean * sc;
 }
 
 template <typename T, bool EVAL>
@@ -220,6 +228,8 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
   const int lane = threadIdx.x & 63;
   const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (c >= C) return;
+  const float g = coeff ? gamma[c] : 0.f, is = coeff ? invstd[c] : 0.f;       // scalars first (latency under the partial loads)
+  const float db0 = (accumulate && dbeta) ? dbeta[c] : 0.f, dg0 = (accumulate && dgamma) ? dgamma[c] : 0.f;
   float q1[16], q2[16];
 #pragma unroll
   for (int j = 0; j < 16; ++j) {
@@ -232,9 +242,9 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) { s1 += __shfl_down(s1, o, 64); s2 += __shfl_down(s2, o, 64); }
   if (lane != 0) return;
-  if (dbeta) dbeta[c] = (accumulate ? dbeta[c] : 0.f) + s1;
-  if (dgamma) dgamma[c] = (accumulate ? dgamma[c] : 0.f) + s2;
-  if (coeff) { coeff[c] = gamma[c] * invstd[c]; coeff[C + c] = s1 * inv_rows; coeff[2 * C + c] = s2 * inv_rows; }
+  if (dbeta) dbeta[c] = db0 + s1;
+  if (dgamma) dgamma[c] = dg0 + s2;
+  if (coeff) { coeff[c] = g * is; coeff[C + c] = s1 * inv_rows; coeff[2 * C + c] = s2 * inv_rows; }
 }
 
 template <typename T>
@@ -320,6 +330,27 @@ extern "C" int mi355_bn_train_fwd(const void* x, const void* residual, void* y, 
   if (dtype == MI355_BF16) hipLaunchKernelGGL((bn_apply_kernel<bf16_t, false>), ga, dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)residual, (bf16_t*)y, (const float*)ss, nf, nf, nf, nf, eps, rows, C, p.TX, relu);
   else hipLaunchKernelGGL((bn_apply_kernel<float, false>), ga, dim3(256), 0, st, (const float*)x, (const float*)residual, (float*)y, (const float*)ss, nf, nf, nf, nf, eps, rows, C, p.TX, relu);
   MI_CHECK_LAUNCH("bn_train_fwd");
+  return MI355_OK;
+}
+
+// Same as mi355_bn_train_fwd, but the per-channel statistics partials [nslices][C][n, mean, M2] were already produced
+// by the convolution that wrote x (mi355_conv_fwd_stats / mi355_conv_dgrad_stats): no statistics pass over x.
+extern "C" int mi355_bn_train_fwd_partials(const void* x, const void* residual, void* y, const float* gamma, const float* beta,
+                                           float* running_mean, float* running_var, int64_t* nbt, float* save_mean,
+                                           float* save_invstd, long rows, int C, float eps, float momentum, int stat_updates,
+                                           int relu, int dtype, const float* partial, int nslices, float* scale_shift,
+                                           void* stream) {
+  int CH; if (int e = bn_check(rows, C, dtype, &CH)) return e;
+  if (stat_updates < 0 || stat_updates > 8) MI_FAIL(MI355_EINVAL, "bn_train_fwd_partials: stat_updates=%d", stat_updates);
+  if (!partial || nslices < 1 || !scale_shift) MI_FAIL(MI355_EINVAL, "bn_train_fwd_partials: partial / scale_shift missing");
+  hipStream_t st = as_stream(stream);
+  BnPlan p = bn_plan(rows, C, CH);
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 4)), dim3(256), 0, st, partial, nslices, C, gamma, beta, running_mean, running_var, nbt, save_mean, save_invstd, scale_shift, eps, momentum, stat_updates);
+  dim3 ga = apply_grid(p, rows);
+  const float* nf = nullptr;
+  if (dtype == MI355_BF16) hipLaunchKernelGGL((bn_apply_kernel<bf16_t, false>), ga, dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)residual, (bf16_t*)y, (const float*)scale_shift, nf, nf, nf, nf, eps, rows, C, p.TX, relu);
+  else hipLaunchKernelGGL((bn_apply_kernel<float, false>), ga, dim3(256), 0, st, (const float*)x, (const float*)residual, (float*)y, (const float*)scale_shift, nf, nf, nf, nf, eps, rows, C, p.TX, relu);
+  MI_CHECK_LAUNCH("bn_train_fwd_partials");
   return MI355_OK;
 }
 

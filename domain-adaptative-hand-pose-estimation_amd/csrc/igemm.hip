@@ -28,6 +28,9 @@ struct GatherArgs {
   int nphase, ntn, ntiles;     // ntiles = nphase * max_phase(ntm) * ntn
   int hw;                      // heat-map output mode: pixels per image
   unsigned a_bytes, b_bytes;
+  size_t stat_bytes;           // (host) capacity of stat_partial
+  int stat_slices;             // (host) slices the launch writes: nphase * ntm, 0 when the statistics were not fused
+  float* stat_partial;         // BatchNorm statistics of the OUTPUT fused into the epilogue: [m-tile slice][Nout][n, mean, M2]
   Phase ph[4];
   Tap taps[MAX_TAPS];
 };
@@ -300,6 +303,12 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gather_gemm_kernel(const Gathe
   constexpr int CPR = BN / CH;  // 16-byte chunks per tile row
   T* __restrict__ D = reinterpret_cast<T*>(p.D);
   const T* __restrict__ R = reinterpret_cast<const T*>(p.residual);
+  // Optional fused BatchNorm statistics of the tile just produced (per output channel over the tile's valid rows, Welford):
+  // every thread already holds the rounded values it streams out, so the statistics cost no extra LDS or HBM reads.
+  const bool stats = p.stat_partial != nullptr;
+  float sn = 0.f, smean[CH], sm2[CH];
+#pragma unroll
+  for (int e = 0; e < CH; ++e) { smean[e] = 0.f; sm2[e] = 0.f; }
   for (int id = t; id < BM * CPR; id += NTHR) {
     const int r = id / CPR, c = id % CPR;
     const int off = row_off[r];
@@ -308,6 +317,11 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gather_gemm_kernel(const Gathe
     float v[CH];
     Chunk<T>::load(reinterpret_cast<const T*>(outs + r * SM::kOutStride + c * 16), v);
     const size_t g = (size_t)off + n;
+    if (stats) {
+      sn += 1.f; const float inv = 1.f / sn;
+#pragma unroll
+      for (int e = 0; e < CH; ++e) { const float d = v[e] - smean[e]; smean[e] += d * inv; sm2[e] += d * (v[e] - smean[e]); }
+    }
     if (R) { float w[CH]; Chunk<T>::load(R + g, w);
 #pragma unroll
       for (int e = 0; e < CH; ++e) v[e] += w[e]; }
@@ -315,6 +329,47 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gather_gemm_kernel(const Gathe
 #pragma unroll
       for (int e = 0; e < CH; ++e) v[e] += w[e]; }
     Chunk<T>::store(D + g, v);
+  }
+  if (stats) {
+    // thread t owns chunk column t % CPR and the rows t / CPR + k * (NTHR / CPR).  Fold the row lanes: inside a wave by
+    // shuffle-down (lower lane = left operand), across the waves through LDS in wave order (fixed order: reproducible).
+    constexpr int NW = NTHR / 64;
+#pragma unroll
+    for (int o = CPR; o < 64; o <<= 1) {
+      const float nb = __shfl_down(sn, o, 64);
+      const float nt = sn + nb, f = nt > 0.f ? nb / nt : 0.f;
+#pragma unroll
+      for (int e = 0; e < CH; ++e) {
+        const float mb = __shfl_down(smean[e], o, 64), vb = __shfl_down(sm2[e], o, 64);
+        const float d = mb - smean[e];
+        smean[e] += d * f; sm2[e] += vb + d * d * sn * f;
+      }
+      sn = nt;
+    }
+    __syncthreads();                                   // everyone is done reading the staged tile
+    float* sp = reinterpret_cast<float*>(smem);        // [NW][BN][3]
+    static_assert(NW * BN * 3 * 4 <= SM::kBytes - BM * 4, "statistics scratch must fit in the tile staging area");
+    if (lane < CPR && lane < 64) {
+      const int c = t % CPR;
+#pragma unroll
+      for (int e = 0; e < CH; ++e) {
+        float* q = sp + ((size_t)wave * BN + c * CH + e) * 3;
+        q[0] = sn; q[1] = smean[e]; q[2] = sm2[e];
+      }
+    }
+    __syncthreads();
+    if (t < BN && n0 + t < p.Nout) {
+      float n = 0.f, mean = 0.f, m2 = 0.f;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) {
+        const float* q = sp + ((size_t)w * BN + t) * 3;
+        const float nb = q[0];
+        if (nb > 0.f) { const float nt = n + nb, f = nb / nt, d = q[1] - mean; mean += d * f; m2 += q[2] + d * d * n * f; n = nt; }
+      }
+      const int slice = (tile / p.ntn) * p.nphase + phi;
+      float* out = p.stat_partial + ((size_t)slice * p.Nout + n0 + t) * 3;
+      out[0] = n; out[1] = mean; out[2] = m2;
+    }
   }
 }
 
@@ -715,6 +770,13 @@ static void launch_gather(GatherArgs& a, hipStream_t st) {
   int mx = 0;
   for (int i = 0; i < a.nphase; ++i) { a.ph[i].ntm = cdiv(a.ph[i].M, BM); if (a.ph[i].ntm > mx) mx = a.ph[i].ntm; }
   a.ntiles = a.nphase * mx * a.ntn;
+  a.stat_slices = 0;
+  if (a.stat_partial) {
+    bool even = !HM_OUT && !a.residual && !a.accumulate;        // phases of unequal tile count would leave unwritten slices
+    for (int i = 0; i < a.nphase; ++i) even = even && a.ph[i].ntm == mx;
+    if (even && (size_t)a.nphase * mx * a.Nout * 3 * sizeof(float) <= a.stat_bytes) a.stat_slices = a.nphase * mx;
+    else a.stat_partial = nullptr;
+  }
   constexpr int smem = GatherSmem<T, BM, BN, DMA ? 2 : 1>::kBytes;
   auto kern = gather_gemm_kernel<T, BM, BN, SMALL_C, WGM, WGN, HM_OUT, DMA>;
   static bool attr_set = false;   // raise the dynamic-LDS cap once per instantiation
@@ -782,8 +844,8 @@ static int check_desc(const mi355_conv_desc* d) {
   return MI355_OK;
 }
 
-extern "C" int mi355_conv_fwd(const mi355_conv_desc* d, const void* x, const void* w, const float* bias,
-                              const void* residual, void* y, void* stream) {
+static int conv_fwd_impl(const mi355_conv_desc* d, const void* x, const void* w, const float* bias, const void* residual, void* y,
+                         float* partial, size_t partial_bytes, int* nslices, void* stream) {
   if (int e = check_desc(d)) return e;
   GatherArgs a; memset(&a, 0, sizeof(a));
   a.A = x; a.B = w; a.D = y; a.bias = bias; a.residual = residual; a.scale = nullptr;
@@ -791,10 +853,24 @@ extern "C" int mi355_conv_fwd(const mi355_conv_desc* d, const void* x, const voi
   a.Ho = d->Ho; a.Wo = d->Wo; a.out_sy = a.out_sx = 1;
   a.Nout = d->Co; a.ldd = d->Co; a.ldb = d->kh * d->kw * d->Ci; a.accumulate = 0;
   a.nphase = 1; a.ph[0].OHp = d->Ho; a.ph[0].OWp = d->Wo; a.ph[0].M = d->N * d->Ho * d->Wo; a.ph[0].ntaps = d->kh * d->kw;
+  a.stat_partial = partial; a.stat_bytes = partial_bytes;
   for (int i = 0; i < d->kh; ++i)
     for (int j = 0; j < d->kw; ++j) { Tap& t = a.taps[i * d->kw + j]; t.dy = (int8_t)(i - d->pad); t.dx = (int8_t)(j - d->pad); t.widx = (int16_t)(i * d->kw + j); }
-  return d->dtype == MI355_BF16 ? dispatch_gather<bf16_t>(a, as_stream(stream)) : dispatch_gather<float>(a, as_stream(stream));
+  int e = d->dtype == MI355_BF16 ? dispatch_gather<bf16_t>(a, as_stream(stream)) : dispatch_gather<float>(a, as_stream(stream));
+  if (nslices) *nslices = a.stat_slices;
+  return e;
 }
+extern "C" int mi355_conv_fwd(const mi355_conv_desc* d, const void* x, const void* w, const float* bias,
+                              const void* residual, void* y, void* stream) {
+  return conv_fwd_impl(d, x, w, bias, residual, y, nullptr, 0, nullptr, stream);
+}
+extern "C" int mi355_conv_fwd_stats(const mi355_conv_desc* d, const void* x, const void* w, const float* bias, void* y,
+                                    float* partial, size_t partial_bytes, int* nslices, void* stream) {
+  if (!partial || !nslices) MI_FAIL(MI355_EINVAL, "conv_fwd_stats: partial / nslices must be given");
+  return conv_fwd_impl(d, x, w, bias, nullptr, y, partial, partial_bytes, nslices, stream);
+}
+// capacity that always suffices for the fused statistics of a conv output / deconv output (smallest tile = 64 rows)
+extern "C" size_t mi355_conv_stats_bytes(long rows, int C) { return (size_t)(rows / 64 + 8) * C * 3 * sizeof(float); }
 
 // 1x1 conv C -> K (K <= 32) written as NCHW fp32 heat-maps: y[n][k][p] = bias[k] + sum_c x[n*HW+p][c] * w[k][c]
 template <typename T>
@@ -827,8 +903,21 @@ extern "C" int mi355_conv1x1_heatmap(const void* x, const void* w, const float* 
 
 // conv-form dgrad: dx[n][iy][ix][ci] = sum_{kh,kw,co} dy[n][(iy+p-kh)/s][(ix+p-kw)/s][co] * w[co][kh][kw][ci]
 // decomposed into stride^2 phases (iy%s, ix%s), each a unit-stride gather over its own tap subset.
+static int conv_dgrad_impl(const mi355_conv_desc* d, const void* dy, const void* wT, const float* bias, const float* scale_dev,
+                           int accumulate, void* dx, float* partial, size_t partial_bytes, int* nslices, void* stream);
 extern "C" int mi355_conv_dgrad(const mi355_conv_desc* d, const void* dy, const void* wT, const float* bias,
                                 const float* scale_dev, int accumulate, void* dx, void* stream) {
+  return conv_dgrad_impl(d, dy, wT, bias, scale_dev, accumulate, dx, nullptr, 0, nullptr, stream);
+}
+// ConvTranspose2d forward (= conv-form dgrad) with the BatchNorm statistics of its output fused into the epilogue
+extern "C" int mi355_conv_dgrad_stats(const mi355_conv_desc* d, const void* dy, const void* wT, void* dx, float* partial,
+                                      size_t partial_bytes, int* nslices, void* stream) {
+  if (!partial || !nslices) MI_FAIL(MI355_EINVAL, "conv_dgrad_stats: partial / nslices must be given");
+  return conv_dgrad_impl(d, dy, wT, nullptr, nullptr, 0, dx, partial, partial_bytes, nslices, stream);
+}
+static int conv_dgrad_impl(const mi355_conv_desc* d, const void* dy, const void* wT, const float* bias, const float* scale_dev,
+                           int accumulate, void* dx, float* partial, size_t partial_bytes, int* nslices, void* stream) {
+  if (nslices) *nslices = 0;
   if (int e = check_desc(d)) return e;
   hipStream_t st = as_stream(stream);
   const int s = d->stride;
@@ -875,8 +964,13 @@ extern "C" int mi355_conv_dgrad(const mi355_conv_desc* d, const void* dy, const 
     }
   if (a.nphase == 0) return MI355_OK;
   static const int merge = getenv("MI355_PHASES") ? atoi(getenv("MI355_PHASES")) : 1;   // 0: one launch per phase (A/B)
-  if (merge || a.nphase == 1)
-    return d->dtype == MI355_BF16 ? dispatch_gather<bf16_t>(a, st) : dispatch_gather<float>(a, st);
+  if (merge || a.nphase == 1) {
+    // statistics only when every output pixel is produced by this launch (no zero-filled phase)
+    if (partial && !need_zero && a.nphase == s * s) { a.stat_partial = partial; a.stat_bytes = partial_bytes; }
+    int e = d->dtype == MI355_BF16 ? dispatch_gather<bf16_t>(a, st) : dispatch_gather<float>(a, st);
+    if (nslices) *nslices = a.stat_slices;
+    return e;
+  }
   const int np = a.nphase;
   for (int i = 0; i < np; ++i) {
     GatherArgs b = a; b.nphase = 1; b.ph[0] = a.ph[i];

@@ -34,6 +34,9 @@ SIGNATURES = {
     'mi355_last_error': (ctypes.c_char_p, []),
     'mi355_conv_fwd': (_I, [_D, _P, _P, _P, _P, _P, _P]),
     'mi355_conv_dgrad': (_I, [_D, _P, _P, _P, _P, _I, _P, _P]),
+    'mi355_conv_stats_bytes': (_Z, [_L, _I]),
+    'mi355_conv_fwd_stats': (_I, [_D, _P, _P, _P, _P, _P, _Z, _P, _P]),
+    'mi355_conv_dgrad_stats': (_I, [_D, _P, _P, _P, _P, _Z, _P, _P]),
     'mi355_conv_wgrad_workspace': (_Z, [_D]),
     'mi355_conv_wgrad': (_I, [_D, _P, _P, _P, _I, _P, _Z, _P]),
     'mi355_pack_weights': (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
@@ -41,6 +44,7 @@ SIGNATURES = {
     'mi355_colsum': (_I, [_P, _P, _L, _I, _I, _I, _P, _Z, _P]),
     'mi355_bn_workspace': (_Z, [_L, _I]),
     'mi355_bn_train_fwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _F, _F, _I, _I, _I, _P, _Z, _P]),
+    'mi355_bn_train_fwd_partials': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _F, _F, _I, _I, _I, _P, _I, _P, _P]),
     'mi355_bn_eval_fwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _L, _I, _F, _I, _I, _P]),
     'mi355_bn_bwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _L, _I, _I, _I, _P, _Z, _P]),
     'mi355_maxpool_fwd': (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),

@@ -90,14 +90,27 @@ def _chk_convform(weight):
 
 # ---------------------------------------------------------------- autograd functions
 import os as _os
+_FUSE_STATS = _os.environ.get('MI355_BN_STATS_FUSE', '1') == '1'      # A/B switch: BN statistics in the conv epilogue
 _SKIP_FUSE = _os.environ.get('MI355_SKIP_FUSE', '1') == '1'             # A/B switch: residual-fork gradient add inside dgrad
 _MASK_FROM_Y = _os.environ.get('MI355_BN_MASK_FROM_Y', '0') == '1'     # A/B switch: read y for every ReLU mask
+
+def _take_partial(mod, y):
+    """Move the statistics partials a conv's forward left on its module onto the output tensor (read by BatchNorm2d)."""
+    part = mod._last_partial
+    if part is not None:
+        mod._last_partial = None
+        y._mi_bn_partial = part
+    return y
+
 
 class _ConvFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, residual, mod, scale_dev):
         desc, wf, _ = mod._plan(x)
-        y = ops.conv_fwd(desc, x, wf, bias, residual)
+        if mod._want_stats() and residual is None:
+            y, mod._last_partial = ops.conv_fwd_stats(desc, x, wf, bias)
+        else:
+            y = ops.conv_fwd(desc, x, wf, bias, residual)
         ctx.mod, ctx.desc, ctx.scale_dev = mod, desc, scale_dev
         ctx.has_bias = bias is not None
         ctx.save_for_backward(x, weight, bias)
@@ -129,7 +142,10 @@ class _ConvSkipFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, mod):
         desc, wf, _ = mod._plan(x)
-        y = ops.conv_fwd(desc, x, wf, None, None)
+        if mod._want_stats():
+            y, mod._last_partial = ops.conv_fwd_stats(desc, x, wf, None)
+        else:
+            y = ops.conv_fwd(desc, x, wf, None, None)
         ctx.mod, ctx.desc = mod, desc
         ctx.save_for_backward(x, weight)
         return y, x
@@ -157,7 +173,10 @@ class _DeconvFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, mod):
         desc, wf, wt = mod._plan(x)
-        y = ops.conv_dgrad(desc, x, wt)
+        if mod._want_stats():
+            y, mod._last_partial = ops.conv_dgrad_stats(desc, x, wt)
+        else:
+            y = ops.conv_dgrad(desc, x, wt)
         ctx.mod, ctx.desc = mod, desc
         ctx.save_for_backward(x, weight)
         return y
@@ -183,9 +202,10 @@ class _DeconvFn(torch.autograd.Function):
 
 class _BnFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, gamma, beta, residual, mod, relu):
+    def forward(ctx, x, gamma, beta, residual, mod, relu, partial=None):
         y, mean, invstd = ops.bn_train_fwd(x, residual, gamma, beta, mod.running_mean, mod.running_var,
-                                           mod.num_batches_tracked, mod.eps, mod.momentum, relu, _rt.bn_stat_updates)
+                                           mod.num_batches_tracked, mod.eps, mod.momentum, relu, _rt.bn_stat_updates,
+                                           partial=partial)
         ctx.relu = relu
         # the ReLU mask is recomputed from x in backward unless a residual was added (then it needs y)
         keep_y = relu and (residual is not None or _MASK_FROM_Y)
@@ -204,7 +224,7 @@ class _BnFn(torch.autograd.Function):
             db, acc_b = grad_slot(beta)
             acc = acc_b if dg is None else acc
         dx, dres = ops.bn_bwd(dy, x, y, gamma, mean, invstd, dg, db, acc, ctx.relu, ctx.needs_input_grad[3], beta=beta)
-        return (dx if ctx.needs_input_grad[0] else None), None, None, dres, None, None
+        return (dx if ctx.needs_input_grad[0] else None), None, None, dres, None, None, None
 
 
 class _MaxPoolFn(torch.autograd.Function):
@@ -340,6 +360,8 @@ class Conv2d(nn.Module):
         self._packed = _PackedWeights()
         self._cast = _CastCopy()
         self._stem_tmp = None
+        self._last_partial = None
+        self.bn_follows = False        # set by link_conv_bn(): the next op is a BatchNorm2d over this conv's output
         self.reset_parameters()
 
     def reset_parameters(self):   # nn.Conv2d defaults
@@ -364,6 +386,10 @@ class Conv2d(nn.Module):
     def _cin_pad(self, dtype):
         per = 8 if dtype == torch.bfloat16 else 4
         return ((self.in_channels + per - 1) // per) * per
+
+    def _want_stats(self):
+        """Training-mode convs hand the BatchNorm that follows them its statistics partials (fused epilogue)."""
+        return _FUSE_STATS and self.training and self.bn_follows
 
     def _plan(self, x):
         N, C, H, W = x.shape
@@ -411,7 +437,7 @@ class Conv2d(nn.Module):
                             dtype, self._cin_pad(dtype))
         else:
             x = _as_feature(x, dtype)
-        return _ConvFn.apply(x, self.weight, self.bias, residual, self, scale)
+        return _take_partial(self, _ConvFn.apply(x, self.weight, self.bias, residual, self, scale))
 
     def forward_skip(self, x):
         """(conv(x), alias of x): for residual blocks, see _ConvSkipFn.  Bias-free MFMA convs only."""
@@ -419,7 +445,8 @@ class Conv2d(nn.Module):
                 self.in_channels != self._cin_pad(compute_dtype()):
             return self.forward(x), x
         x = _as_feature(x, compute_dtype())
-        return _ConvSkipFn.apply(x, self.weight, self)
+        y, skip = _ConvSkipFn.apply(x, self.weight, self)
+        return _take_partial(self, y), skip
 
 
 class ConvTranspose2d(nn.Module):
@@ -435,6 +462,8 @@ class ConvTranspose2d(nn.Module):
         self.weight = _convform_param(in_channels, out_channels, kernel_size, kernel_size)
         self.bias = None
         self._packed = _PackedWeights()
+        self._last_partial = None
+        self.bn_follows = False
         nn.init.kaiming_uniform_(self.weight, a=math.sqrt(5))
 
     def _plan(self, x):
@@ -450,7 +479,10 @@ class ConvTranspose2d(nn.Module):
 
     def forward(self, x):
         x = _as_feature(x, compute_dtype())
-        return _DeconvFn.apply(x, self.weight, self)
+        return _take_partial(self, _DeconvFn.apply(x, self.weight, self))
+
+    def _want_stats(self):
+        return _FUSE_STATS and self.training and self.bn_follows
 
 
 class BatchNorm2d(nn.Module):
@@ -469,7 +501,10 @@ class BatchNorm2d(nn.Module):
     def forward(self, x, residual=None, relu=False):
         x = _as_feature(x, compute_dtype())
         if self.training:
-            return _BnFn.apply(x, self.weight, self.bias, residual, self, bool(relu))
+            partial = getattr(x, '_mi_bn_partial', None)      # statistics partials from the conv that produced x
+            if partial is not None and (x.shape[1] != self.num_features or not ops.is_nhwc(x)):
+                partial = None
+            return _BnFn.apply(x, self.weight, self.bias, residual, self, bool(relu), partial)
         if torch.is_grad_enabled() and (x.requires_grad or self.weight.requires_grad):
             raise Mi355Error('BatchNorm2d in eval mode is forward-only on this path (wrap it in torch.no_grad())')
         return ops.bn_eval_fwd(x, residual, self.weight, self.bias, self.running_mean, self.running_var, self.eps, relu)
@@ -496,9 +531,23 @@ class MaxPool2d(nn.Module):
         return _MaxPoolFn.apply(_as_feature(x, compute_dtype()))
 
 
+def link_conv_bn(module):
+    """Mark every conv / deconv child that is directly followed (in registration order) by a BatchNorm2d child: in training
+    mode such a conv computes the BatchNorm statistics of its output in its epilogue.  Only a hint -- the BatchNorm uses the
+    partials solely when they arrive attached to the very tensor it normalises."""
+    kids = list(module.children())
+    for a, b in zip(kids, kids[1:]):
+        if isinstance(a, (Conv2d, ConvTranspose2d)) and isinstance(b, BatchNorm2d):
+            a.bn_follows = getattr(a, 'mode', 'mfma') == 'mfma'
+
+
 class FusedSequential(nn.Sequential):
     """nn.Sequential with the same child indices (state_dict keys) that runs [BatchNorm2d, ReLU] pairs as one
     fused kernel."""
+
+    def __init__(self, *args):
+        super().__init__(*args)
+        link_conv_bn(self)
 
     def forward(self, x):
         mods = list(self)

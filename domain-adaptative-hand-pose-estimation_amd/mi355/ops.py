@@ -67,6 +67,33 @@ def conv_fwd(desc, x, w, bias=None, residual=None):
     return y
 
 
+def _stats_buf(rows, C, device):
+    nbytes = load().mi355_conv_stats_bytes(rows, C)
+    return torch.empty(nbytes // 4, dtype=torch.float32, device=device), nbytes
+
+
+def conv_fwd_stats(desc, x, w, bias=None):
+    """conv forward + BatchNorm statistics partials of y from the epilogue.  Returns (y, (partial, nslices) | None)."""
+    _chk_dev(x, w)
+    y = nhwc_empty(desc.N, desc.Co, desc.Ho, desc.Wo, x.dtype, x.device)
+    partial, nbytes = _stats_buf(desc.N * desc.Ho * desc.Wo, desc.Co, x.device)
+    ns = ctypes.c_int(0)
+    call('mi355_conv_fwd_stats', ctypes.byref(desc), ptr(x), ptr(w), ptr(bias), ptr(y), ptr(partial), nbytes,
+         ctypes.byref(ns), stream_ptr())
+    return y, ((partial, ns.value) if ns.value > 0 else None)
+
+
+def conv_dgrad_stats(desc, dy, wT):
+    """ConvTranspose2d forward (conv-form dgrad) + BatchNorm statistics partials of its output."""
+    _chk_dev(dy, wT)
+    dx = nhwc_empty(desc.N, desc.Ci, desc.Hi, desc.Wi, dy.dtype, dy.device)
+    partial, nbytes = _stats_buf(desc.N * desc.Hi * desc.Wi, desc.Ci, dy.device)
+    ns = ctypes.c_int(0)
+    call('mi355_conv_dgrad_stats', ctypes.byref(desc), ptr(dy), ptr(wT), ptr(dx), ptr(partial), nbytes,
+         ctypes.byref(ns), stream_ptr())
+    return dx, ((partial, ns.value) if ns.value > 0 else None)
+
+
 def conv_dgrad(desc, dy, wT, scale_dev=None, out=None, accumulate=False):
     _chk_dev(dy, wT)
     dx = out if out is not None else nhwc_empty(desc.N, desc.Ci, desc.Hi, desc.Wi, dy.dtype, dy.device)
@@ -108,13 +135,22 @@ def colsum(dy, out, accumulate):
 
 
 # ---------------------------------------------------------------- batch norm
-def bn_train_fwd(x, residual, gamma, beta, running_mean, running_var, nbt, eps, momentum, relu, stat_updates=1):
+def bn_train_fwd(x, residual, gamma, beta, running_mean, running_var, nbt, eps, momentum, relu, stat_updates=1,
+                 partial=None):
+    """partial: (buffer, nslices) from conv_fwd_stats / conv_dgrad_stats of the conv that produced x -> no statistics pass."""
     _chk_dev(x, gamma)
     N, C, H, W = x.shape
     rows = N * H * W
     y = nhwc_empty(N, C, H, W, x.dtype, x.device)
     mean = torch.empty(C, dtype=torch.float32, device=x.device)
     invstd = torch.empty(C, dtype=torch.float32, device=x.device)
+    if partial is not None:
+        buf, ns = partial
+        ss = torch.empty(2 * C, dtype=torch.float32, device=x.device)
+        call('mi355_bn_train_fwd_partials', ptr(x), ptr(residual), ptr(y), ptr(gamma), ptr(beta), ptr(running_mean),
+             ptr(running_var), ptr(nbt), ptr(mean), ptr(invstd), rows, C, float(eps), float(momentum), int(stat_updates),
+             int(relu), dtype_code(x.dtype), ptr(buf), int(ns), ptr(ss), stream_ptr())
+        return y, mean, invstd
     ws = workspace(load().mi355_bn_workspace(rows, C), x.device)
     call('mi355_bn_train_fwd', ptr(x), ptr(residual), ptr(y), ptr(gamma), ptr(beta), ptr(running_mean),
          ptr(running_var), ptr(nbt), ptr(mean), ptr(invstd), rows, C, float(eps), float(momentum), int(stat_updates), int(relu),

@@ -17,7 +17,7 @@ import warnings
 import torch
 import torch.nn as nn
 
-from mi355.nn import Conv2d, BatchNorm2d, ReLU, MaxPool2d, FusedSequential
+from mi355.nn import Conv2d, BatchNorm2d, ReLU, MaxPool2d, FusedSequential, link_conv_bn
 
 __all__ = ['ResNet', 'resnet18', 'resnet34', 'resnet50', 'resnet101', 'resnet152']
 
@@ -34,6 +34,7 @@ class BasicBlock(nn.Module):
         self.bn2 = BatchNorm2d(planes)
         self.downsample = downsample
         self.stride = stride
+        link_conv_bn(self)
 
     def forward(self, x):
         out, skip = self.conv1.forward_skip(x)     # skip aliases x; its gradient is summed inside conv1's dgrad
@@ -56,6 +57,7 @@ class Bottleneck(nn.Module):
         self.relu = ReLU(inplace=True)
         self.downsample = downsample
         self.stride = stride
+        link_conv_bn(self)
 
     def forward(self, x):
         out, skip = self.conv1.forward_skip(x)     # skip aliases x; its gradient is summed inside conv1's dgrad
@@ -88,6 +90,7 @@ class ResNet(nn.Module):
                 nn.init.constant_(m.weight, 1)
                 nn.init.constant_(m.bias, 0)
         self._out_features = self.fc.in_features
+        link_conv_bn(self)
 
     def _make_layer(self, block, planes, blocks, stride=1):
         downsample = None

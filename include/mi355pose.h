@@ -70,6 +70,15 @@ int mi355_conv_fwd(const mi355_conv_desc* d, const void* x, const void* w, const
                    const void* residual, void* y, void* stream);
 int mi355_conv_dgrad(const mi355_conv_desc* d, const void* dy, const void* wT, const float* bias,
                      const float* scale_dev, int accumulate, void* dx, void* stream);
+/* Convolution / transposed-convolution forward with the BatchNorm batch statistics of its OUTPUT computed in the
+ * epilogue (the nn.BatchNorm2d that follows every conv of resnet.py / pose_resnet2.py:33-41 / regda_7.py:4906-4929 in
+ * training mode): partial[slice][Co|Ci][n, mean, M2] per output-row tile, *nslices = slices written (0: this launch
+ * could not fuse them -- the caller then runs mi355_bn_train_fwd).  partial_bytes >= mi355_conv_stats_bytes(rows, C). */
+size_t mi355_conv_stats_bytes(long rows, int C);
+int mi355_conv_fwd_stats(const mi355_conv_desc* d, const void* x, const void* w, const float* bias, void* y,
+                         float* partial, size_t partial_bytes, int* nslices, void* stream);
+int mi355_conv_dgrad_stats(const mi355_conv_desc* d, const void* dy, const void* wT, void* dx, float* partial,
+                           size_t partial_bytes, int* nslices, void* stream);
 size_t mi355_conv_wgrad_workspace(const mi355_conv_desc* d);
 int mi355_conv_wgrad(const mi355_conv_desc* d, const void* x, const void* dy, float* dw, int accumulate,
                      void* ws, size_t ws_bytes, void* stream);
@@ -100,6 +109,13 @@ int mi355_bn_train_fwd(const void* x, const void* residual, void* y, const float
                        float* running_mean, float* running_var, int64_t* num_batches_tracked,
                        float* save_mean, float* save_invstd, long rows, int C, float eps, float momentum,
                        int stat_updates, int relu, int dtype, void* ws, size_t ws_bytes, void* stream);
+/* mi355_bn_train_fwd without its statistics pass: the partials come from mi355_conv_fwd_stats / _dgrad_stats.
+ * scale_shift: 2*C floats of scratch. */
+int mi355_bn_train_fwd_partials(const void* x, const void* residual, void* y, const float* gamma, const float* beta,
+                                float* running_mean, float* running_var, int64_t* num_batches_tracked,
+                                float* save_mean, float* save_invstd, long rows, int C, float eps, float momentum,
+                                int stat_updates, int relu, int dtype, const float* partial, int nslices,
+                                float* scale_shift, void* stream);
 int mi355_bn_eval_fwd(const void* x, const void* residual, void* y, const float* gamma, const float* beta,
                       const float* running_mean, const float* running_var, long rows, int C, float eps,
                       int relu, int dtype, void* stream);

@@ -115,6 +115,53 @@ def test_conv_residual_epilogue(gpu, dt):
     assert float((_back(y) - ref).abs().max()) <= _tol(dt, ref)
 
 
+STAT_CASES = [
+    # kind, N, Ci, H, W, Co, k, s, p   (kind 'conv': Conv2d; 'deconv': conv-form of ConvTranspose2d(Co -> Ci, 4, 2, 1))
+    ('conv', 2, 64, 16, 16, 128, 3, 1, 1),
+    ('conv', 3, 128, 8, 8, 256, 1, 1, 0),
+    ('conv', 2, 64, 16, 16, 128, 3, 2, 1),
+    ('conv', 2, 3, 32, 32, 64, 7, 2, 3),       # stem (padded input channels, small-C kernel variant)
+    ('conv', 1, 64, 9, 13, 64, 3, 1, 1),       # ragged: partial row tiles
+    ('conv', 6, 64, 40, 40, 128, 1, 1, 0),     # 9600 rows: 128-row tiles
+    ('deconv', 2, 256, 16, 16, 64, 4, 2, 1),   # four output phases in one launch
+]
+
+
+@pytest.mark.parametrize('dt', ['f32', 'bf16'])
+@pytest.mark.parametrize('case', STAT_CASES)
+def test_conv_epilogue_bn_statistics(gpu, dt, case):
+    """BatchNorm statistics fused into the conv / deconv epilogue == the stand-alone statistics pass over the same output."""
+    ops = _ops()
+    kind, N, Ci, H, W, Co, k, s, p = case
+    per = 8 if dt == 'bf16' else 4
+    Cip = ((Ci + per - 1) // per) * per
+    desc = ops.make_desc(N, H, W, Cip, Co, k, k, s, p, DT[dt])
+    w = _round(randn(2, Co, Ci, k, k, scale=1.0 / np.sqrt(Ci * k * k)), dt)
+    wf, wt = ops.pack_weights(w.permute(0, 2, 3, 1).contiguous().to(gpu), Co, k * k, Ci, Cip, DT[dt])
+    if kind == 'conv':
+        x = _nhwc(_round(randn(1, N, Ci, H, W) + 0.4, dt), dt, gpu, Cip)
+        y, part = ops.conv_fwd_stats(desc, x, wf)
+        y0 = ops.conv_fwd(desc, x, wf)
+    else:
+        x = _nhwc(_round(randn(1, N, Co, desc.Ho, desc.Wo) + 0.4, dt), dt, gpu)
+        y, part = ops.conv_dgrad_stats(desc, x, wt)
+        y0 = ops.conv_dgrad(desc, x, wt)
+    assert part is not None and part[1] >= 1
+    assert torch.equal(y, y0)                        # the fused epilogue leaves the conv result untouched
+    C = y.shape[1]
+    gamma, beta = (1 + 0.1 * randn(23, C)).to(gpu), (0.1 * randn(24, C)).to(gpu)
+    outs = []
+    for pp in (None, part):
+        rm, rv = torch.zeros(C, device=gpu), torch.ones(C, device=gpu)
+        nbt = torch.zeros((), dtype=torch.int64, device=gpu)
+        outs.append(ops.bn_train_fwd(y, None, gamma, beta, rm, rv, nbt, 1e-5, 0.1, True, partial=pp) + (rm, rv, nbt))
+    (ya, ma, ia, rma, rva, na), (yb, mb, ib, rmb, rvb, nb) = outs
+    assert int(na) == int(nb) == 1
+    assert torch.allclose(ma, mb, rtol=1e-5, atol=1e-6) and torch.allclose(ia, ib, rtol=2e-5, atol=1e-6)
+    assert torch.allclose(rma, rmb, rtol=1e-5, atol=1e-6) and torch.allclose(rva, rvb, rtol=2e-5, atol=1e-6)
+    assert float((ya.float() - yb.float()).abs().max()) <= (2e-2 if dt == 'bf16' else 1e-4)   # bf16: one-ulp flips at most
+
+
 @pytest.mark.parametrize('dt', ['f32', 'bf16'])
 @pytest.mark.parametrize('shape', [(4, 64, 16, 16), (2, 256, 8, 8), (3, 2048, 4, 4), (2, 24, 5, 7)])
 @pytest.mark.parametrize('relu,res', [(True, False), (True, True), (False, False)])
