@@ -230,15 +230,17 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
   if (c >= C) return;
   const float g = coeff ? gamma[c] : 0.f, is = coeff ? invstd[c] : 0.f;       // scalars first (latency under the partial loads)
   const float db0 = (accumulate && dbeta) ? dbeta[c] : 0.f, dg0 = (accumulate && dgamma) ? dgamma[c] : 0.f;
-  float q1[16], q2[16];
-#pragma unroll
-  for (int j = 0; j < 16; ++j) {
-    const int s = lane + 64 * j;
-    if (s < nslices) { const float* q = partial + ((size_t)s * C + c) * 2; q1[j] = q[0]; q2[j] = q[1]; } else { q1[j] = 0.f; q2[j] = 0.f; }
-  }
   float s1 = 0.f, s2 = 0.f;
+  for (int base = 0; base < nslices; base += 1024) {     // (conv-fused reductions can bring more than 1024 slices)
+    float q1[16], q2[16];
 #pragma unroll
-  for (int j = 0; j < 16; ++j) { s1 += q1[j]; s2 += q2[j]; }
+    for (int j = 0; j < 16; ++j) {
+      const int s = base + lane + 64 * j;
+      if (s < nslices) { const float* q = partial + ((size_t)s * C + c) * 2; q1[j] = q[0]; q2[j] = q[1]; } else { q1[j] = 0.f; q2[j] = 0.f; }
+    }
+#pragma unroll
+    for (int j = 0; j < 16; ++j) { s1 += q1[j]; s2 += q2[j]; }
+  }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) { s1 += __shfl_down(s1, o, 64); s2 += __shfl_down(s2, o, 64); }
   if (lane != 0) return;
@@ -389,6 +391,26 @@ extern "C" int mi355_bn_bwd(const void* dy, const void* x, const void* y, const 
   if (dtype == MI355_BF16) hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, ga, dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)x, (const bf16_t*)y, save_mean, save_invstd, coeff, beta, (bf16_t*)dx, (bf16_t*)dresidual, rows, C, p.TX, relu);
   else hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, ga, dim3(256), 0, st, (const float*)dy, (const float*)x, (const float*)y, save_mean, save_invstd, coeff, beta, (float*)dx, (float*)dresidual, rows, C, p.TX, relu);
   MI_CHECK_LAUNCH("bn_bwd");
+  return MI355_OK;
+}
+
+// mi355_bn_bwd without its reduction pass: (sum dy_eff, sum dy_eff*xhat) partials [nslices][C][2] came out of the epilogue
+// of the GEMM that produced dy (mi355_conv_dgrad_bnbwd / mi355_conv_fwd_bnbwd).  coeff: 3*C floats of scratch.
+extern "C" int mi355_bn_bwd_partials(const void* dy, const void* x, const void* y, const float* gamma, const float* beta,
+                                     const float* save_mean, const float* save_invstd, void* dx, void* dresidual, float* dgamma,
+                                     float* dbeta, int accumulate, long rows, int C, int relu, int dtype, const float* partial,
+                                     int nslices, float* coeff, void* stream) {
+  int CH; if (int e = bn_check(rows, C, dtype, &CH)) return e;
+  if (!partial || nslices < 1 || !coeff) MI_FAIL(MI355_EINVAL, "bn_bwd_partials: partial / coeff missing");
+  if (relu) relu = y ? 1 : 2;
+  if (relu == 2 && !beta) MI_FAIL(MI355_EINVAL, "bn_bwd_partials: relu without y needs beta");
+  hipStream_t st = as_stream(stream);
+  BnPlan p = bn_plan(rows, C, CH);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 4)), dim3(256), 0, st, partial, nslices, C, 1.0f / (float)rows, gamma, save_invstd, dgamma, dbeta, accumulate, coeff);
+  dim3 ga = apply_grid(p, rows);
+  if (dtype == MI355_BF16) hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, ga, dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)x, (const bf16_t*)y, save_mean, save_invstd, coeff, beta, (bf16_t*)dx, (bf16_t*)dresidual, rows, C, p.TX, relu);
+  else hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, ga, dim3(256), 0, st, (const float*)dy, (const float*)x, (const float*)y, save_mean, save_invstd, coeff, beta, (float*)dx, (float*)dresidual, rows, C, p.TX, relu);
+  MI_CHECK_LAUNCH("bn_bwd_partials");
   return MI355_OK;
 }
 

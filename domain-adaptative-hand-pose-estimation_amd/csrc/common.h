@@ -45,15 +45,17 @@ template <> struct Chunk<float> {
     float4 q = *reinterpret_cast<const float4*>(p); v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w; }
   __device__ static inline void store(float* p, const float (&v)[4]) {
     *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]); }
+  __device__ static inline void unpack(const uint4& q, float (&v)[4]) {
+    v[0] = __uint_as_float(q.x); v[1] = __uint_as_float(q.y); v[2] = __uint_as_float(q.z); v[3] = __uint_as_float(q.w); }
 };
 template <> struct Chunk<bf16_t> {
   static constexpr int N = 8;
-  __device__ static inline void load(const bf16_t* p, float (&v)[8]) {
-    uint4 q = *reinterpret_cast<const uint4*>(p);
+  __device__ static inline void unpack(const uint4& q, float (&v)[8]) {
     unsigned w[4] = {q.x, q.y, q.z, q.w};
 #pragma unroll
     for (int i = 0; i < 4; ++i) { v[2 * i] = __uint_as_float(w[i] << 16); v[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u); }
   }
+  __device__ static inline void load(const bf16_t* p, float (&v)[8]) { unpack(*reinterpret_cast<const uint4*>(p), v); }
   __device__ static inline void store(bf16_t* p, const float (&v)[8]) {
     union { bf16_t h[8]; uint4 q; } u;
 #pragma unroll

@@ -30,6 +30,12 @@ struct GatherArgs {
   unsigned a_bytes, b_bytes;
   size_t stat_bytes;           // (host) capacity of stat_partial
   int stat_slices;             // (host) slices the launch writes: nphase * ntm, 0 when the statistics were not fused
+  // BatchNorm BACKWARD reduction fused into the epilogue: this launch produces dy of a BatchNorm whose input was bnb_x
+  // (same shape as D); per m-tile slice and channel it leaves (sum dy_eff, sum dy_eff * xhat) in bnb_partial[slice][Nout][2].
+  // bnb_relu: 0 none, 1 mask from bnb_y > 0, 2 mask recomputed from bnb_x (see bn.hip).
+  const void* bnb_x; const void* bnb_y;
+  const float* bnb_mean; const float* bnb_invstd; const float* bnb_gamma; const float* bnb_beta;
+  float* bnb_partial; int bnb_relu;
   float* stat_partial;         // BatchNorm statistics of the OUTPUT fused into the epilogue: [m-tile slice][Nout][n, mean, M2]
   Phase ph[4];
   Tap taps[MAX_TAPS];
@@ -74,7 +80,9 @@ struct GatherSmem {
 // HM_OUT: the result is written as NCHW fp32 heat-maps [image][Nout][hw] (the 1x1 conv to the K=21 key-point maps).
 // DMA: K-tiles travel global -> LDS directly (buffer_load ... lds, 1 KiB per wave-instruction, out-of-range lanes deliver
 //      zeros) into a 2-stage ring: no staging registers, no ds_write, one barrier per K-tile.
-template <typename T, int BM, int BN, bool SMALL_C, int WGM = 2, int WGN = 2, bool HM_OUT = false, bool DMA = false>
+// EPI: epilogue extras, compiled separately so the plain kernel keeps its register budget (3 blocks per CU):
+//      0 plain, 1 + BatchNorm statistics of the output, 2 + BatchNorm-backward reduction of the output.
+template <typename T, int BM, int BN, bool SMALL_C, int WGM = 2, int WGN = 2, bool HM_OUT = false, bool DMA = false, int EPI = 0>
 __global__ __launch_bounds__(64 * WGM * WGN) void gather_gemm_kernel(const GatherArgs p) {
   constexpr int CH = MmaTraits<T>::CH;
   constexpr int NTHR = 64 * WGM * WGN, RPP = NTHR / 8;      // rows staged per pass (8 lanes = one 128-byte row)
@@ -234,6 +242,8 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gather_gemm_kernel(const Gathe
       __builtin_amdgcn_s_setprio(0);
     }
   } else {
+    // (two K-tiles in flight for the small tiles -- 64x128 and below have the registers -- measured: no gain on the
+    //  latency-bound mid-size layers, occupancy 5 -> 3; per-K-step issue cost, not prefetch depth, bounds them)
     load_tile(0, ra0, rb0);
     for (int kt = 0; kt < nk; ++kt) {
       __syncthreads(); store_tile(ra0, rb0); __syncthreads();
@@ -305,30 +315,122 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gather_gemm_kernel(const Gathe
   const T* __restrict__ R = reinterpret_cast<const T*>(p.residual);
   // Optional fused BatchNorm statistics of the tile just produced (per output channel over the tile's valid rows, Welford):
   // every thread already holds the rounded values it streams out, so the statistics cost no extra LDS or HBM reads.
-  const bool stats = p.stat_partial != nullptr;
-  float sn = 0.f, smean[CH], sm2[CH];
+  constexpr bool stats = EPI == 1, bnb = EPI == 2;
+  float sn = 0.f, smean[CH], sm2[CH];      // bnb mode reuses smean / sm2 as the two running sums
+  float bmu[CH], bis[CH], bsc[CH], bsh[CH];
 #pragma unroll
-  for (int e = 0; e < CH; ++e) { smean[e] = 0.f; sm2[e] = 0.f; }
-  for (int id = t; id < BM * CPR; id += NTHR) {
-    const int r = id / CPR, c = id % CPR;
-    const int off = row_off[r];
-    const int n = n0 + c * CH;
-    if (off < 0 || n >= p.Nout) continue;
-    float v[CH];
-    Chunk<T>::load(reinterpret_cast<const T*>(outs + r * SM::kOutStride + c * 16), v);
-    const size_t g = (size_t)off + n;
-    if (stats) {
-      sn += 1.f; const float inv = 1.f / sn;
+  for (int e = 0; e < CH; ++e) { smean[e] = 0.f; sm2[e] = 0.f; bmu[e] = 0.f; bis[e] = 0.f; bsc[e] = 0.f; bsh[e] = 0.f; }
+  const T* __restrict__ BX = reinterpret_cast<const T*>(p.bnb_x);
+  const T* __restrict__ BY = reinterpret_cast<const T*>(p.bnb_y);
+  if (bnb) {
+    const int n = n0 + (t % CPR) * CH;
+    if (n < p.Nout) {
 #pragma unroll
-      for (int e = 0; e < CH; ++e) { const float d = v[e] - smean[e]; smean[e] += d * inv; sm2[e] += d * (v[e] - smean[e]); }
+      for (int e = 0; e < CH; ++e) {
+        bmu[e] = p.bnb_mean[n + e]; bis[e] = p.bnb_invstd[n + e];
+        if (p.bnb_relu == 2) { bsc[e] = p.bnb_gamma[n + e] * bis[e]; bsh[e] = p.bnb_beta[n + e] - bmu[e] * bsc[e]; }
+      }
     }
-    if (R) { float w[CH]; Chunk<T>::load(R + g, w);
+  }
+  if constexpr (!bnb) {
+    // rows streamed one at a time, loads interleaved with the stores (measured faster than fetching all rows' addends
+    // up front: 44 vs 49 us on the 256->64 1x1 dgrad @64x64)
+    for (int id = t; id < BM * CPR; id += NTHR) {
+      const int r = id / CPR, c = id % CPR;
+      const int off = row_off[r];
+      const int n = n0 + c * CH;
+      if (off < 0 || n >= p.Nout) continue;
+      float v[CH];
+      Chunk<T>::load(reinterpret_cast<const T*>(outs + r * SM::kOutStride + c * 16), v);
+      const size_t g = (size_t)off + n;
+      if (stats) {
+        sn += 1.f; const float inv = 1.f / sn;
 #pragma unroll
-      for (int e = 0; e < CH; ++e) v[e] += w[e]; }
-    if (p.accumulate) { float w[CH]; Chunk<T>::load(D + g, w);
+        for (int e = 0; e < CH; ++e) { const float d = v[e] - smean[e]; smean[e] += d * inv; sm2[e] += d * (v[e] - smean[e]); }
+      }
+      if (R) { float w[CH]; Chunk<T>::load(R + g, w);
 #pragma unroll
-      for (int e = 0; e < CH; ++e) v[e] += w[e]; }
-    Chunk<T>::store(D + g, v);
+        for (int e = 0; e < CH; ++e) v[e] += w[e]; }
+      if (p.accumulate) { float w[CH]; Chunk<T>::load(D + g, w);
+#pragma unroll
+        for (int e = 0; e < CH; ++e) v[e] += w[e]; }
+      Chunk<T>::store(D + g, v);
+    }
+  } else {
+    // EPI == 2 (own register budget, 2 blocks per CU): every global operand of the epilogue -- the addend and the
+    // BatchNorm's x / y -- is fetched for all of this thread's rows before any is used: one latency instead of one per row
+    constexpr int IT = BM * CPR / NTHR;
+    static_assert(BM * CPR % NTHR == 0, "whole passes only");
+    const int ec = t % CPR, er0 = t / CPR;
+    const int en = n0 + ec * CH;
+    const bool ecok = en < p.Nout;
+    int eoff[IT];
+    uint4 qa[IT], qx[IT], qy[IT];
+    const T* __restrict__ ADD = R ? R : (p.accumulate ? D : nullptr);
+#pragma unroll
+    for (int k = 0; k < IT; ++k) {
+      const int off = row_off[er0 + k * (NTHR / CPR)];
+      eoff[k] = (off >= 0 && ecok) ? off + en : -1;
+      if (eoff[k] >= 0) {
+        if (ADD) qa[k] = *reinterpret_cast<const uint4*>(ADD + (size_t)eoff[k]);
+        qx[k] = *reinterpret_cast<const uint4*>(BX + (size_t)eoff[k]);
+        if (p.bnb_relu == 1) qy[k] = *reinterpret_cast<const uint4*>(BY + (size_t)eoff[k]);
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < IT; ++k) {
+      if (eoff[k] < 0) continue;
+      const int r = er0 + k * (NTHR / CPR);
+      float v[CH];
+      Chunk<T>::load(reinterpret_cast<const T*>(outs + r * SM::kOutStride + ec * 16), v);
+      const size_t g = (size_t)eoff[k];
+      if (ADD) { float w[CH]; Chunk<T>::unpack(qa[k], w);
+#pragma unroll
+        for (int e = 0; e < CH; ++e) v[e] += w[e]; }
+      if (R && p.accumulate) { float w[CH]; Chunk<T>::load(D + g, w);      // (both at once: not used by this model)
+#pragma unroll
+        for (int e = 0; e < CH; ++e) v[e] += w[e]; }
+      Chunk<T>::store(D + g, v);
+      // same arithmetic as bn_bwd_reduce_kernel, on the value as stored (rounded to T)
+      float xv[CH], gq[CH]; Chunk<T>::unpack(qx[k], xv);
+#pragma unroll
+      for (int e = 0; e < CH; ++e) gq[e] = (float)(T)v[e];
+      if (p.bnb_relu == 1) { float yv[CH]; Chunk<T>::unpack(qy[k], yv);
+#pragma unroll
+        for (int e = 0; e < CH; ++e) gq[e] = yv[e] > 0.f ? gq[e] : 0.f; }
+      else if (p.bnb_relu == 2) {
+#pragma unroll
+        for (int e = 0; e < CH; ++e) gq[e] = (xv[e] * bsc[e] + bsh[e]) > 0.f ? gq[e] : 0.f; }
+#pragma unroll
+      for (int e = 0; e < CH; ++e) { smean[e] += gq[e]; sm2[e] += gq[e] * ((xv[e] - bmu[e]) * bis[e]); }
+    }
+  }
+  if (bnb) {
+    constexpr int NW = NTHR / 64;
+#pragma unroll
+    for (int o = CPR; o < 64; o <<= 1) {
+#pragma unroll
+      for (int e = 0; e < CH; ++e) { smean[e] += __shfl_down(smean[e], o, 64); sm2[e] += __shfl_down(sm2[e], o, 64); }
+    }
+    __syncthreads();
+    float* sp = reinterpret_cast<float*>(smem);        // [NW][BN][2]
+    if (lane < CPR) {
+#pragma unroll
+      for (int e = 0; e < CH; ++e) {
+        float* q = sp + ((size_t)wave * BN + (t % CPR) * CH + e) * 2;
+        q[0] = smean[e]; q[1] = sm2[e];
+      }
+    }
+    __syncthreads();
+    if (t < BN && n0 + t < p.Nout) {
+      float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) { a1 += sp[((size_t)w * BN + t) * 2]; a2 += sp[((size_t)w * BN + t) * 2 + 1]; }
+      const int slice = (tile / p.ntn) * p.nphase + phi;
+      float* out = p.bnb_partial + ((size_t)slice * p.Nout + n0 + t) * 2;
+      out[0] = a1; out[1] = a2;
+    }
+    return;
   }
   if (stats) {
     // thread t owns chunk column t % CPR and the rows t / CPR + k * (NTHR / CPR).  Fold the row lanes: inside a wave by
@@ -764,6 +866,15 @@ __global__ void zero_fill_kernel(uint4* __restrict__ p, size_t n16) {
 // ------------------------------------------------------------------------------------ host side
 static int ilog2_exact(int v) { int s = 0; while ((1 << s) < v) ++s; return ((1 << s) == v) ? s : -1; }
 
+template <typename T, int BM, int BN, bool SMALL_C, int WGM, int WGN, bool HM_OUT, bool DMA, int EPI>
+static void launch_gather_epi(const GatherArgs& a, hipStream_t st) {
+  constexpr int smem = GatherSmem<T, BM, BN, DMA ? 2 : 1>::kBytes;
+  auto kern = gather_gemm_kernel<T, BM, BN, SMALL_C, WGM, WGN, HM_OUT, DMA, EPI>;
+  static bool attr_set = false;   // raise the dynamic-LDS cap once per instantiation
+  if (!attr_set) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem); attr_set = true; }
+  hipLaunchKernelGGL(kern, dim3(a.ntiles), dim3(64 * WGM * WGN), smem, st, a);
+}
+
 template <typename T, int BM, int BN, bool SMALL_C, int WGM = 2, int WGN = 2, bool HM_OUT = false, bool DMA = false>
 static void launch_gather(GatherArgs& a, hipStream_t st) {
   a.ntn = cdiv(a.Nout, BN);
@@ -777,11 +888,19 @@ static void launch_gather(GatherArgs& a, hipStream_t st) {
     if (even && (size_t)a.nphase * mx * a.Nout * 3 * sizeof(float) <= a.stat_bytes) a.stat_slices = a.nphase * mx;
     else a.stat_partial = nullptr;
   }
-  constexpr int smem = GatherSmem<T, BM, BN, DMA ? 2 : 1>::kBytes;
-  auto kern = gather_gemm_kernel<T, BM, BN, SMALL_C, WGM, WGN, HM_OUT, DMA>;
-  static bool attr_set = false;   // raise the dynamic-LDS cap once per instantiation
-  if (!attr_set) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem); attr_set = true; }
-  hipLaunchKernelGGL(kern, dim3(a.ntiles), dim3(64 * WGM * WGN), smem, st, a);
+  if (a.bnb_partial) {
+    bool even = !HM_OUT && !a.stat_partial;
+    for (int i = 0; i < a.nphase; ++i) even = even && a.ph[i].ntm == mx;
+    if (even && (size_t)a.nphase * mx * a.Nout * 2 * sizeof(float) <= a.stat_bytes) a.stat_slices = a.nphase * mx;
+    else a.bnb_partial = nullptr;
+  }
+  constexpr bool EXTRAS = !HM_OUT && BM <= 128;     // the epilogue variants exist for the regular tiles only
+  if (!EXTRAS && (a.stat_partial || a.bnb_partial)) { a.stat_partial = nullptr; a.bnb_partial = nullptr; a.stat_slices = 0; }
+  if constexpr (EXTRAS) {
+    if (a.bnb_partial) { launch_gather_epi<T, BM, BN, SMALL_C, WGM, WGN, HM_OUT, DMA, 2>(a, st); return; }
+    if (a.stat_partial) { launch_gather_epi<T, BM, BN, SMALL_C, WGM, WGN, HM_OUT, DMA, 1>(a, st); return; }
+  }
+  launch_gather_epi<T, BM, BN, SMALL_C, WGM, WGN, HM_OUT, DMA, 0>(a, st);
 }
 
 template <typename T>
@@ -844,8 +963,20 @@ static int check_desc(const mi355_conv_desc* d) {
   return MI355_OK;
 }
 
+static void set_bnb(GatherArgs& a, const mi355_bn_bwd_src* bn, float* partial, size_t partial_bytes) {
+  a.bnb_x = bn->x; a.bnb_y = bn->relu ? bn->y : nullptr;
+  a.bnb_mean = bn->save_mean; a.bnb_invstd = bn->save_invstd; a.bnb_gamma = bn->gamma; a.bnb_beta = bn->beta;
+  a.bnb_relu = bn->relu ? (bn->y ? 1 : 2) : 0;
+  a.bnb_partial = partial; a.stat_bytes = partial_bytes;
+}
+static int check_bnb(const mi355_bn_bwd_src* bn, const float* partial, const int* nslices) {
+  if (!bn || !partial || !nslices || !bn->x || !bn->save_mean || !bn->save_invstd)
+    MI_FAIL(MI355_EINVAL, "bnbwd fusion: bn source / partial / nslices must be given");
+  if (bn->relu && !bn->y && (!bn->gamma || !bn->beta)) MI_FAIL(MI355_EINVAL, "bnbwd fusion: relu without y needs gamma and beta");
+  return MI355_OK;
+}
 static int conv_fwd_impl(const mi355_conv_desc* d, const void* x, const void* w, const float* bias, const void* residual, void* y,
-                         float* partial, size_t partial_bytes, int* nslices, void* stream) {
+                         float* partial, size_t partial_bytes, int* nslices, void* stream, const mi355_bn_bwd_src* bn = nullptr) {
   if (int e = check_desc(d)) return e;
   GatherArgs a; memset(&a, 0, sizeof(a));
   a.A = x; a.B = w; a.D = y; a.bias = bias; a.residual = residual; a.scale = nullptr;
@@ -853,7 +984,8 @@ static int conv_fwd_impl(const mi355_conv_desc* d, const void* x, const void* w,
   a.Ho = d->Ho; a.Wo = d->Wo; a.out_sy = a.out_sx = 1;
   a.Nout = d->Co; a.ldd = d->Co; a.ldb = d->kh * d->kw * d->Ci; a.accumulate = 0;
   a.nphase = 1; a.ph[0].OHp = d->Ho; a.ph[0].OWp = d->Wo; a.ph[0].M = d->N * d->Ho * d->Wo; a.ph[0].ntaps = d->kh * d->kw;
-  a.stat_partial = partial; a.stat_bytes = partial_bytes;
+  if (bn) set_bnb(a, bn, partial, partial_bytes);
+  else { a.stat_partial = partial; a.stat_bytes = partial_bytes; }
   for (int i = 0; i < d->kh; ++i)
     for (int j = 0; j < d->kw; ++j) { Tap& t = a.taps[i * d->kw + j]; t.dy = (int8_t)(i - d->pad); t.dx = (int8_t)(j - d->pad); t.widx = (int16_t)(i * d->kw + j); }
   int e = d->dtype == MI355_BF16 ? dispatch_gather<bf16_t>(a, as_stream(stream)) : dispatch_gather<float>(a, as_stream(stream));
@@ -868,6 +1000,12 @@ extern "C" int mi355_conv_fwd_stats(const mi355_conv_desc* d, const void* x, con
                                     float* partial, size_t partial_bytes, int* nslices, void* stream) {
   if (!partial || !nslices) MI_FAIL(MI355_EINVAL, "conv_fwd_stats: partial / nslices must be given");
   return conv_fwd_impl(d, x, w, bias, nullptr, y, partial, partial_bytes, nslices, stream);
+}
+// ConvTranspose2d input gradient (= conv-form forward) producing the dy of a BatchNorm: its backward reduction in the epilogue
+extern "C" int mi355_conv_fwd_bnbwd(const mi355_conv_desc* d, const void* x, const void* w, void* y, const mi355_bn_bwd_src* bn,
+                                    float* partial, size_t partial_bytes, int* nslices, void* stream) {
+  if (int e = check_bnb(bn, partial, nslices)) return e;
+  return conv_fwd_impl(d, x, w, nullptr, nullptr, y, partial, partial_bytes, nslices, stream, bn);
 }
 // capacity that always suffices for the fused statistics of a conv output / deconv output (smallest tile = 64 rows)
 extern "C" size_t mi355_conv_stats_bytes(long rows, int C) { return (size_t)(rows / 64 + 8) * C * 3 * sizeof(float); }
@@ -904,7 +1042,15 @@ extern "C" int mi355_conv1x1_heatmap(const void* x, const void* w, const float* 
 // conv-form dgrad: dx[n][iy][ix][ci] = sum_{kh,kw,co} dy[n][(iy+p-kh)/s][(ix+p-kw)/s][co] * w[co][kh][kw][ci]
 // decomposed into stride^2 phases (iy%s, ix%s), each a unit-stride gather over its own tap subset.
 static int conv_dgrad_impl(const mi355_conv_desc* d, const void* dy, const void* wT, const float* bias, const float* scale_dev,
-                           int accumulate, void* dx, float* partial, size_t partial_bytes, int* nslices, void* stream);
+                           int accumulate, void* dx, float* partial, size_t partial_bytes, int* nslices, void* stream,
+                           const mi355_bn_bwd_src* bn = nullptr);
+// conv input gradient that is the dy of a BatchNorm: that BatchNorm's backward reduction in the epilogue
+extern "C" int mi355_conv_dgrad_bnbwd(const mi355_conv_desc* d, const void* dy, const void* wT, const float* scale_dev, int accumulate,
+                                      void* dx, const mi355_bn_bwd_src* bn, float* partial, size_t partial_bytes, int* nslices,
+                                      void* stream) {
+  if (int e = check_bnb(bn, partial, nslices)) return e;
+  return conv_dgrad_impl(d, dy, wT, nullptr, scale_dev, accumulate, dx, partial, partial_bytes, nslices, stream, bn);
+}
 extern "C" int mi355_conv_dgrad(const mi355_conv_desc* d, const void* dy, const void* wT, const float* bias,
                                 const float* scale_dev, int accumulate, void* dx, void* stream) {
   return conv_dgrad_impl(d, dy, wT, bias, scale_dev, accumulate, dx, nullptr, 0, nullptr, stream);
@@ -916,7 +1062,8 @@ extern "C" int mi355_conv_dgrad_stats(const mi355_conv_desc* d, const void* dy, 
   return conv_dgrad_impl(d, dy, wT, nullptr, nullptr, 0, dx, partial, partial_bytes, nslices, stream);
 }
 static int conv_dgrad_impl(const mi355_conv_desc* d, const void* dy, const void* wT, const float* bias, const float* scale_dev,
-                           int accumulate, void* dx, float* partial, size_t partial_bytes, int* nslices, void* stream) {
+                           int accumulate, void* dx, float* partial, size_t partial_bytes, int* nslices, void* stream,
+                           const mi355_bn_bwd_src* bn) {
   if (nslices) *nslices = 0;
   if (int e = check_desc(d)) return e;
   hipStream_t st = as_stream(stream);
@@ -966,7 +1113,8 @@ static int conv_dgrad_impl(const mi355_conv_desc* d, const void* dy, const void*
   static const int merge = getenv("MI355_PHASES") ? atoi(getenv("MI355_PHASES")) : 1;   // 0: one launch per phase (A/B)
   if (merge || a.nphase == 1) {
     // statistics only when every output pixel is produced by this launch (no zero-filled phase)
-    if (partial && !need_zero && a.nphase == s * s) { a.stat_partial = partial; a.stat_bytes = partial_bytes; }
+    if (bn) set_bnb(a, bn, partial, partial_bytes);   // (zero-filled phases carry dy = 0: they add nothing to the sums)
+    else if (partial && !need_zero && a.nphase == s * s) { a.stat_partial = partial; a.stat_bytes = partial_bytes; }
     int e = d->dtype == MI355_BF16 ? dispatch_gather<bf16_t>(a, st) : dispatch_gather<float>(a, st);
     if (nslices) *nslices = a.stat_slices;
     return e;

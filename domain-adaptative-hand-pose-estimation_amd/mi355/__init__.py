@@ -26,6 +26,12 @@ class ConvDesc(ctypes.Structure):
                 ('N', 'Hi', 'Wi', 'Ci', 'Ho', 'Wo', 'Co', 'kh', 'kw', 'stride', 'pad', 'dtype')]
 
 
+class BnBwdSrc(ctypes.Structure):
+    """mi355_bn_bwd_src: saved forward state of the BatchNorm whose dy a GEMM epilogue reduces."""
+    _fields_ = [('x', ctypes.c_void_p), ('y', ctypes.c_void_p), ('gamma', ctypes.c_void_p), ('beta', ctypes.c_void_p),
+                ('save_mean', ctypes.c_void_p), ('save_invstd', ctypes.c_void_p), ('relu', ctypes.c_int)]
+
+
 # name -> (restype, argtypes); mirrors include/mi355pose.h one to one
 _P, _I, _L, _F, _Z = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_float, ctypes.c_size_t
 _D = ctypes.POINTER(ConvDesc)
@@ -37,6 +43,8 @@ SIGNATURES = {
     'mi355_conv_stats_bytes': (_Z, [_L, _I]),
     'mi355_conv_fwd_stats': (_I, [_D, _P, _P, _P, _P, _P, _Z, _P, _P]),
     'mi355_conv_dgrad_stats': (_I, [_D, _P, _P, _P, _P, _Z, _P, _P]),
+    'mi355_conv_dgrad_bnbwd': (_I, [_D, _P, _P, _P, _I, _P, _P, _P, _Z, _P, _P]),
+    'mi355_conv_fwd_bnbwd': (_I, [_D, _P, _P, _P, _P, _P, _Z, _P, _P]),
     'mi355_conv_wgrad_workspace': (_Z, [_D]),
     'mi355_conv_wgrad': (_I, [_D, _P, _P, _P, _I, _P, _Z, _P]),
     'mi355_pack_weights': (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
@@ -46,6 +54,7 @@ SIGNATURES = {
     'mi355_bn_train_fwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _F, _F, _I, _I, _I, _P, _Z, _P]),
     'mi355_bn_train_fwd_partials': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _F, _F, _I, _I, _I, _P, _I, _P, _P]),
     'mi355_bn_eval_fwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _L, _I, _F, _I, _I, _P]),
+    'mi355_bn_bwd_partials': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _L, _I, _I, _I, _P, _I, _P, _P]),
     'mi355_bn_bwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _L, _I, _I, _I, _P, _Z, _P]),
     'mi355_maxpool_fwd': (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
     'mi355_maxpool_bwd': (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),

@@ -35,6 +35,7 @@ def mark_grads_fresh(params):
     for p in params:
         if p.grad is not None:
             p._mi_fresh = True
+    _BWD_PARTIALS.clear()          # leftovers of a backward pass that never reached their BatchNorm
 
 
 def _param_version(p):
@@ -91,8 +92,31 @@ def _chk_convform(weight):
 # ---------------------------------------------------------------- autograd functions
 import os as _os
 _FUSE_STATS = _os.environ.get('MI355_BN_STATS_FUSE', '1') == '1'      # A/B switch: BN statistics in the conv epilogue
+_FUSE_BNBWD = _os.environ.get('MI355_BN_BWD_FUSE', '0') == '1'        # opt-in: BN backward reduction in the dgrad epilogue (measured neutral)
 _SKIP_FUSE = _os.environ.get('MI355_SKIP_FUSE', '1') == '1'             # A/B switch: residual-fork gradient add inside dgrad
 _MASK_FROM_Y = _os.environ.get('MI355_BN_MASK_FROM_Y', '0') == '1'     # A/B switch: read y for every ReLU mask
+
+# dy tensors whose producing GEMM already reduced them for the BatchNorm backward: data_ptr -> (dy, (partial, nslices)).
+# The entry keeps dy alive, so its address cannot be reused while the entry exists; BatchNorm's backward pops it.
+_BWD_PARTIALS = {}
+
+
+def _bn_src_of(x):
+    """Saved forward state of the training-mode BatchNorm that produced x (None if x is anything else)."""
+    return getattr(x, '_mi_bn_src', None) if _FUSE_BNBWD else None
+
+
+def _dgrad_for_bn(desc, dy, wt, src, x_in, scale_dev=None, out=None, accumulate=False):
+    """conv input gradient; when the conv input was a BatchNorm output, reduce it for that BatchNorm on the way out."""
+    if src is None:
+        return ops.conv_dgrad(desc, dy, wt, scale_dev=scale_dev, out=out, accumulate=accumulate)
+    xb, need_y, gamma, beta, mean, invstd, relu = src
+    dx, part = ops.conv_dgrad_bnbwd(desc, dy, wt, (xb, x_in if need_y else None, gamma, beta, mean, invstd, relu),
+                                    scale_dev=scale_dev, out=out, accumulate=accumulate)
+    if part is not None:
+        _BWD_PARTIALS[dx.data_ptr()] = (dx, part)
+    return dx
+
 
 def _take_partial(mod, y):
     """Move the statistics partials a conv's forward left on its module onto the output tensor (read by BatchNorm2d)."""
@@ -112,6 +136,7 @@ class _ConvFn(torch.autograd.Function):
         else:
             y = ops.conv_fwd(desc, x, wf, bias, residual)
         ctx.mod, ctx.desc, ctx.scale_dev = mod, desc, scale_dev
+        ctx.bn_src = mod._in_bn_src; mod._in_bn_src = None
         ctx.has_bias = bias is not None
         ctx.save_for_backward(x, weight, bias)
         return y
@@ -126,7 +151,7 @@ class _ConvFn(torch.autograd.Function):
             mod._wgrad(desc, x, dy, weight)          # off the critical path: side stream
         if ctx.needs_input_grad[0]:
             _, _, wt = mod._plan(x)
-            dx = ops.conv_dgrad(desc, dy, wt, scale_dev=ctx.scale_dev)
+            dx = _dgrad_for_bn(desc, dy, wt, ctx.bn_src, x, scale_dev=ctx.scale_dev)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             g, acc = grad_slot(bias)
             ops.colsum(dy, g, acc)
@@ -147,6 +172,7 @@ class _ConvSkipFn(torch.autograd.Function):
         else:
             y = ops.conv_fwd(desc, x, wf, None, None)
         ctx.mod, ctx.desc = mod, desc
+        ctx.bn_src = mod._in_bn_src; mod._in_bn_src = None
         ctx.save_for_backward(x, weight)
         return y, x
 
@@ -161,9 +187,9 @@ class _ConvSkipFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             _, _, wt = mod._plan(x)
             if dskip is None:
-                dx = ops.conv_dgrad(desc, dy, wt)
+                dx = _dgrad_for_bn(desc, dy, wt, ctx.bn_src, x)
             else:       # dskip is a gradient buffer this library produced (BN / conv backward): accumulate in place
-                dx = ops.conv_dgrad(desc, dy, wt, out=_as_grad(dskip, x.dtype), accumulate=True)
+                dx = _dgrad_for_bn(desc, dy, wt, ctx.bn_src, x, out=_as_grad(dskip, x.dtype), accumulate=True)
         return dx, None, None
 
 
@@ -178,6 +204,7 @@ class _DeconvFn(torch.autograd.Function):
         else:
             y = ops.conv_dgrad(desc, x, wt)
         ctx.mod, ctx.desc = mod, desc
+        ctx.bn_src = mod._in_bn_src; mod._in_bn_src = None
         ctx.save_for_backward(x, weight)
         return y
 
@@ -196,7 +223,13 @@ class _DeconvFn(torch.autograd.Function):
                 ops.conv_wgrad(desc, dy, x, g, acc)
         if ctx.needs_input_grad[0]:
             _, wf, _ = mod._plan(x)
-            dx = ops.conv_fwd(desc, dy, wf)
+            if ctx.bn_src is None:
+                dx = ops.conv_fwd(desc, dy, wf)
+            else:
+                xb, need_y, gamma, beta, mean, invstd, relu = ctx.bn_src
+                dx, part = ops.conv_fwd_bnbwd(desc, dy, wf, (xb, x if need_y else None, gamma, beta, mean, invstd, relu))
+                if part is not None:
+                    _BWD_PARTIALS[dx.data_ptr()] = (dx, part)
         return dx, None, None
 
 
@@ -210,6 +243,7 @@ class _BnFn(torch.autograd.Function):
         # the ReLU mask is recomputed from x in backward unless a residual was added (then it needs y)
         keep_y = relu and (residual is not None or _MASK_FROM_Y)
         ctx.save_for_backward(x, y if keep_y else None, mean, invstd, gamma, beta)
+        mod._last_src = (x, bool(keep_y), gamma, beta, mean, invstd, bool(relu))
         return y
 
     @staticmethod
@@ -223,7 +257,10 @@ class _BnFn(torch.autograd.Function):
         if ctx.needs_input_grad[2]:
             db, acc_b = grad_slot(beta)
             acc = acc_b if dg is None else acc
-        dx, dres = ops.bn_bwd(dy, x, y, gamma, mean, invstd, dg, db, acc, ctx.relu, ctx.needs_input_grad[3], beta=beta)
+        ent = _BWD_PARTIALS.pop(dy.data_ptr(), None)       # dy already reduced by the GEMM epilogue that produced it?
+        partial = ent[1] if (ent is not None and ent[0].shape == dy.shape and ent[0].dtype == dy.dtype) else None
+        dx, dres = ops.bn_bwd(dy, x, y, gamma, mean, invstd, dg, db, acc, ctx.relu, ctx.needs_input_grad[3], beta=beta,
+                              partial=partial)
         return (dx if ctx.needs_input_grad[0] else None), None, None, dres, None, None, None
 
 
@@ -361,6 +398,7 @@ class Conv2d(nn.Module):
         self._cast = _CastCopy()
         self._stem_tmp = None
         self._last_partial = None
+        self._in_bn_src = None
         self.bn_follows = False        # set by link_conv_bn(): the next op is a BatchNorm2d over this conv's output
         self.reset_parameters()
 
@@ -437,6 +475,7 @@ class Conv2d(nn.Module):
                             dtype, self._cin_pad(dtype))
         else:
             x = _as_feature(x, dtype)
+        self._in_bn_src = _bn_src_of(x)
         return _take_partial(self, _ConvFn.apply(x, self.weight, self.bias, residual, self, scale))
 
     def forward_skip(self, x):
@@ -445,6 +484,7 @@ class Conv2d(nn.Module):
                 self.in_channels != self._cin_pad(compute_dtype()):
             return self.forward(x), x
         x = _as_feature(x, compute_dtype())
+        self._in_bn_src = _bn_src_of(x)
         y, skip = _ConvSkipFn.apply(x, self.weight, self)
         return _take_partial(self, y), skip
 
@@ -463,6 +503,7 @@ class ConvTranspose2d(nn.Module):
         self.bias = None
         self._packed = _PackedWeights()
         self._last_partial = None
+        self._in_bn_src = None
         self.bn_follows = False
         nn.init.kaiming_uniform_(self.weight, a=math.sqrt(5))
 
@@ -479,6 +520,7 @@ class ConvTranspose2d(nn.Module):
 
     def forward(self, x):
         x = _as_feature(x, compute_dtype())
+        self._in_bn_src = _bn_src_of(x)
         return _take_partial(self, _DeconvFn.apply(x, self.weight, self))
 
     def _want_stats(self):
@@ -504,7 +546,9 @@ class BatchNorm2d(nn.Module):
             partial = getattr(x, '_mi_bn_partial', None)      # statistics partials from the conv that produced x
             if partial is not None and (x.shape[1] != self.num_features or not ops.is_nhwc(x)):
                 partial = None
-            return _BnFn.apply(x, self.weight, self.bias, residual, self, bool(relu), partial)
+            y = _BnFn.apply(x, self.weight, self.bias, residual, self, bool(relu), partial)
+            y._mi_bn_src, self._last_src = self._last_src, None     # lets the consumer conv's dgrad reduce dy for this BN
+            return y
         if torch.is_grad_enabled() and (x.requires_grad or self.weight.requires_grad):
             raise Mi355Error('BatchNorm2d in eval mode is forward-only on this path (wrap it in torch.no_grad())')
         return ops.bn_eval_fwd(x, residual, self.weight, self.bias, self.running_mean, self.running_var, self.eps, relu)

@@ -8,7 +8,7 @@ import ctypes
 
 import torch
 
-from . import (ConvDesc, Mi355Error, call, compute_dtype, dtype_code, load, ptr, stream_ptr, workspace)
+from . import (BnBwdSrc, ConvDesc, Mi355Error, call, compute_dtype, dtype_code, load, ptr, stream_ptr, workspace)
 
 
 # ---------------------------------------------------------------- layout helpers
@@ -94,6 +94,37 @@ def conv_dgrad_stats(desc, dy, wT):
     return dx, ((partial, ns.value) if ns.value > 0 else None)
 
 
+def _bn_src(bn):
+    """bn = (x, y_or_None, gamma, beta, mean, invstd, relu) -> BnBwdSrc (the tuple keeps the tensors alive)."""
+    x, y, gamma, beta, mean, invstd, relu = bn
+    return BnBwdSrc(ptr(x), ptr(y), ptr(gamma), ptr(beta), ptr(mean), ptr(invstd), int(bool(relu)))
+
+
+def conv_dgrad_bnbwd(desc, dy, wT, bn, scale_dev=None, out=None, accumulate=False):
+    """conv_dgrad whose result is the dy of the BatchNorm described by `bn`; also returns that BatchNorm's backward
+    reduction partials (buffer, nslices) from the epilogue, or None when the launch could not fuse them."""
+    _chk_dev(dy, wT)
+    dx = out if out is not None else nhwc_empty(desc.N, desc.Ci, desc.Hi, desc.Wi, dy.dtype, dy.device)
+    partial, nbytes = _stats_buf(desc.N * desc.Hi * desc.Wi, desc.Ci, dy.device)
+    ns = ctypes.c_int(0)
+    src = _bn_src(bn)
+    call('mi355_conv_dgrad_bnbwd', ctypes.byref(desc), ptr(dy), ptr(wT), ptr(scale_dev), int(accumulate), ptr(dx),
+         ctypes.byref(src), ptr(partial), nbytes, ctypes.byref(ns), stream_ptr())
+    return dx, ((partial, ns.value) if ns.value > 0 else None)
+
+
+def conv_fwd_bnbwd(desc, x, w, bn):
+    """conv_fwd (the input gradient of a ConvTranspose2d) whose result is the dy of the BatchNorm `bn`."""
+    _chk_dev(x, w)
+    y = nhwc_empty(desc.N, desc.Co, desc.Ho, desc.Wo, x.dtype, x.device)
+    partial, nbytes = _stats_buf(desc.N * desc.Ho * desc.Wo, desc.Co, x.device)
+    ns = ctypes.c_int(0)
+    src = _bn_src(bn)
+    call('mi355_conv_fwd_bnbwd', ctypes.byref(desc), ptr(x), ptr(w), ptr(y), ctypes.byref(src), ptr(partial), nbytes,
+         ctypes.byref(ns), stream_ptr())
+    return y, ((partial, ns.value) if ns.value > 0 else None)
+
+
 def conv_dgrad(desc, dy, wT, scale_dev=None, out=None, accumulate=False):
     _chk_dev(dy, wT)
     dx = out if out is not None else nhwc_empty(desc.N, desc.Ci, desc.Hi, desc.Wi, dy.dtype, dy.device)
@@ -167,11 +198,19 @@ def bn_eval_fwd(x, residual, gamma, beta, running_mean, running_var, eps, relu):
     return y
 
 
-def bn_bwd(dy, x, y, gamma, mean, invstd, dgamma, dbeta, accumulate, relu, want_dres, beta=None):
+def bn_bwd(dy, x, y, gamma, mean, invstd, dgamma, dbeta, accumulate, relu, want_dres, beta=None, partial=None):
+    """partial: (buffer, nslices) reduction partials from the GEMM epilogue that produced dy -> no reduction pass."""
     N, C, H, W = x.shape
     rows = N * H * W
     dx = nhwc_empty(N, C, H, W, x.dtype, x.device)
     dres = nhwc_empty(N, C, H, W, x.dtype, x.device) if want_dres else None
+    if partial is not None:
+        buf, ns = partial
+        coeff = torch.empty(3 * C, dtype=torch.float32, device=x.device)
+        call('mi355_bn_bwd_partials', ptr(dy), ptr(x), ptr(y), ptr(gamma), ptr(beta), ptr(mean), ptr(invstd), ptr(dx),
+             ptr(dres), ptr(dgamma), ptr(dbeta), int(accumulate), rows, C, int(relu), dtype_code(x.dtype), ptr(buf), int(ns),
+             ptr(coeff), stream_ptr())
+        return dx, dres
     ws = workspace(load().mi355_bn_workspace(rows, C), x.device)
     call('mi355_bn_bwd', ptr(dy), ptr(x), ptr(y), ptr(gamma), ptr(beta), ptr(mean), ptr(invstd), ptr(dx), ptr(dres),
          ptr(dgamma), ptr(dbeta), int(accumulate), rows, C, int(relu), dtype_code(x.dtype), ptr(ws), ws.numel(),

@@ -97,7 +97,9 @@ class PoseResNetx9(nn.Module):
         if detach_features:
             with torch.no_grad():
                 return self.upsampling(self.backbone(x))
-        return self.upsampling(self.backbone(x))
+        f = self.upsampling(self.backbone(x))
+        f._mi_bn_src = None      # f feeds four heads: its gradient is a sum, no single dgrad epilogue can reduce it
+        return f
 
     def adv_heads(self, f):
         """The three cascaded adversarial heads behind the gradient layer: f -> (y_adv, y_adv2, y_adv3)."""

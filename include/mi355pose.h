@@ -79,6 +79,19 @@ int mi355_conv_fwd_stats(const mi355_conv_desc* d, const void* x, const void* w,
                          float* partial, size_t partial_bytes, int* nslices, void* stream);
 int mi355_conv_dgrad_stats(const mi355_conv_desc* d, const void* dy, const void* wT, void* dx, float* partial,
                            size_t partial_bytes, int* nslices, void* stream);
+/* The same idea for the BACKWARD pass: a GEMM whose output is the dy of a BatchNorm (the input gradient of the conv
+ * that consumed the BatchNorm's output) leaves that BatchNorm's backward reduction (sum dy_eff, sum dy_eff * xhat) per
+ * output-row tile in partial[slice][C][2]; mi355_bn_bwd_partials then skips its reduction pass.  bn: the BatchNorm's
+ * saved forward state; relu != 0 masks dy with y > 0 (y given) or with the mask recomputed from x (y NULL). */
+typedef struct mi355_bn_bwd_src {
+  const void* x; const void* y; const float* gamma; const float* beta; const float* save_mean; const float* save_invstd;
+  int relu;
+} mi355_bn_bwd_src;
+int mi355_conv_dgrad_bnbwd(const mi355_conv_desc* d, const void* dy, const void* wT, const float* scale_dev, int accumulate,
+                           void* dx, const mi355_bn_bwd_src* bn, float* partial, size_t partial_bytes, int* nslices,
+                           void* stream);
+int mi355_conv_fwd_bnbwd(const mi355_conv_desc* d, const void* x, const void* w, void* y, const mi355_bn_bwd_src* bn,
+                         float* partial, size_t partial_bytes, int* nslices, void* stream);
 size_t mi355_conv_wgrad_workspace(const mi355_conv_desc* d);
 int mi355_conv_wgrad(const mi355_conv_desc* d, const void* x, const void* dy, float* dw, int accumulate,
                      void* ws, size_t ws_bytes, void* stream);
@@ -119,6 +132,10 @@ int mi355_bn_train_fwd_partials(const void* x, const void* residual, void* y, co
 int mi355_bn_eval_fwd(const void* x, const void* residual, void* y, const float* gamma, const float* beta,
                       const float* running_mean, const float* running_var, long rows, int C, float eps,
                       int relu, int dtype, void* stream);
+int mi355_bn_bwd_partials(const void* dy, const void* x, const void* y, const float* gamma, const float* beta,
+                          const float* save_mean, const float* save_invstd, void* dx, void* dresidual, float* dgamma,
+                          float* dbeta, int accumulate, long rows, int C, int relu, int dtype, const float* partial,
+                          int nslices, float* coeff, void* stream);
 int mi355_bn_bwd(const void* dy, const void* x, const void* y, const float* gamma, const float* beta,
                  const float* save_mean, const float* save_invstd, void* dx, void* dresidual, float* dgamma, float* dbeta,
                  int accumulate, long rows, int C, int relu, int dtype, void* ws, size_t ws_bytes,

@@ -439,3 +439,47 @@ def test_device_label_generation_matches_generate_target(gpu):
     t, w = generate_target_device(torch.from_numpy(kp).to(gpu), torch.from_numpy(vis).to(gpu))
     assert np.array_equal(w.cpu().numpy(), ref_w)
     assert np.array_equal(t.cpu().numpy(), ref_t)
+
+
+@pytest.mark.parametrize('dt', ['f32', 'bf16'])
+@pytest.mark.parametrize('mode', ['none', 'mask_x', 'mask_y'])
+@pytest.mark.parametrize('case', [('conv', 2, 64, 16, 16, 128, 3, 1, 1, False), ('conv', 2, 64, 16, 16, 128, 3, 2, 1, True),
+                                  ('conv', 3, 128, 8, 8, 256, 1, 1, 0, False), ('conv', 2, 64, 16, 16, 256, 1, 2, 0, False),
+                                  ('deconv', 2, 256, 16, 16, 64, 4, 2, 1, False)])
+def test_gemm_epilogue_bn_backward_reduction(gpu, dt, mode, case):
+    """dgrad (or the deconv input gradient) that also reduces its result for the BatchNorm it feeds == separate passes."""
+    ops = _ops()
+    kind, N, Ci, H, W, Co, k, s, p, acc = case
+    desc = ops.make_desc(N, H, W, Ci, Co, k, k, s, p, DT[dt])
+    w = _round(randn(2, Co, Ci, k, k, scale=1.0 / np.sqrt(Ci * k * k)), dt)
+    wf, wt = ops.pack_weights(w.permute(0, 2, 3, 1).contiguous().to(gpu), Co, k * k, Ci, Ci, DT[dt])
+    if kind == 'conv':       # the GEMM output has the conv INPUT's shape
+        g_in = _nhwc(_round(randn(1, N, Co, desc.Ho, desc.Wo), dt), dt, gpu)
+        C, Hh, Ww = Ci, H, W
+    else:
+        g_in = _nhwc(_round(randn(1, N, Ci, H, W), dt), dt, gpu)
+        C, Hh, Ww = Co, desc.Ho, desc.Wo
+    xb = _nhwc(_round(randn(5, N, C, Hh, Ww) * 1.3 + 0.2, dt), dt, gpu)        # the BatchNorm's forward input
+    gamma, beta = (1 + 0.1 * randn(23, C)).to(gpu), (0.1 * randn(24, C)).to(gpu)
+    rm, rv, nbt = torch.zeros(C, device=gpu), torch.ones(C, device=gpu), torch.zeros((), dtype=torch.int64, device=gpu)
+    relu = mode != 'none'
+    yb, mean, invstd = ops.bn_train_fwd(xb, None, gamma, beta, rm, rv, nbt, 1e-5, 0.1, relu)
+    y_mask = yb if mode == 'mask_y' else None
+    base = _nhwc(_round(randn(6, N, C, Hh, Ww), dt), dt, gpu) if acc else None
+    bn = (xb, y_mask, gamma, beta, mean, invstd, relu)
+    if kind == 'conv':
+        dy0 = ops.conv_dgrad(desc, g_in, wt, out=base.clone() if acc else None, accumulate=acc)
+        dy1, part = ops.conv_dgrad_bnbwd(desc, g_in, wt, bn, out=base.clone() if acc else None, accumulate=acc)
+    else:
+        dy0 = ops.conv_fwd(desc, g_in, wf)
+        dy1, part = ops.conv_fwd_bnbwd(desc, g_in, wf, bn)
+    assert part is not None and torch.equal(dy0, dy1)
+    res = []
+    for pp in (None, part):
+        dg, db = torch.zeros(C, device=gpu), torch.zeros(C, device=gpu)
+        dx, _ = ops.bn_bwd(dy1, xb, y_mask, gamma, mean, invstd, dg, db, False, relu, False, beta=beta, partial=pp)
+        res.append((dx, dg, db))
+    (dxa, dga, dba), (dxb, dgb, dbb) = res
+    sc = float(dga.abs().max()) + float(dba.abs().max()) + 1.0
+    assert float((dga - dgb).abs().max()) <= 2e-5 * sc and float((dba - dbb).abs().max()) <= 2e-5 * sc
+    assert float((dxa.float() - dxb.float()).abs().max()) <= (2e-2 if dt == 'bf16' else 1e-4) * (float(dxa.float().abs().max()) + 1e-6)
