@@ -1245,6 +1245,47 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, T* __restrict__
     }
 }
 
+// All conv weights of one optimizer group in ONE launch (after the optimizer step): items live in device memory,
+// block b finds its item by binary search over the items' first-block prefix.
+template <typename T>
+__global__ void pack_weights_batched_kernel(const mi355_pack_item* __restrict__ items, int nitems) {
+  __shared__ float tile[32][33];
+  int lo = 0, hi = nitems - 1;
+  const int b = blockIdx.x;
+  while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (items[mid].blk0 <= b) lo = mid; else hi = mid - 1; }
+  const mi355_pack_item it = items[lo];
+  const int O = it.O, Tt = it.T, I = it.I, Ipad = it.Ipad;
+  const int nbi = (Ipad + 31) / 32, nbo = (O + 31) / 32;
+  int q = b - it.blk0;
+  const int bi = q % nbi; q /= nbi;
+  const int bo = q % nbo; const int tap = q / nbo;
+  const float* __restrict__ w = it.w;
+  T* __restrict__ wf = reinterpret_cast<T*>(it.wf);
+  T* __restrict__ wt = reinterpret_cast<T*>(it.wt);
+  const int o0 = bo * 32, i0 = bi * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int r = ty; r < 32; r += 8) {
+    int o = o0 + r, i = i0 + tx;
+    float v = (o < O && i < I) ? w[((size_t)o * Tt + tap) * I + i] : 0.f;
+    tile[r][tx] = v;
+    if (wf && o < O && i < Ipad) Elem<T>::st(wf + ((size_t)o * Tt + tap) * Ipad + i, v);
+  }
+  __syncthreads();
+  if (wt)
+    for (int r = ty; r < 32; r += 8) {
+      int i = i0 + r, o = o0 + tx;
+      if (o < O && i < Ipad) Elem<T>::st(wt + ((size_t)i * Tt + tap) * O + o, tile[tx][r]);
+    }
+}
+extern "C" int mi355_pack_weights_batched(const mi355_pack_item* items_dev, int nitems, int total_blocks, int dtype, void* stream) {
+  if (!items_dev || nitems < 1 || total_blocks < 1) MI_FAIL(MI355_EINVAL, "pack_weights_batched: bad args");
+  if (dtype == MI355_BF16) hipLaunchKernelGGL(pack_weights_batched_kernel<bf16_t>, dim3(total_blocks), dim3(256), 0, as_stream(stream), items_dev, nitems);
+  else if (dtype == MI355_F32) hipLaunchKernelGGL(pack_weights_batched_kernel<float>, dim3(total_blocks), dim3(256), 0, as_stream(stream), items_dev, nitems);
+  else MI_FAIL(MI355_EINVAL, "bad dtype");
+  MI_CHECK_LAUNCH("pack_weights_batched");
+  return MI355_OK;
+}
+
 extern "C" int mi355_pack_weights(const float* w, void* wf, void* wt, int O, int Tt, int I, int Ipad, int dtype, void* stream) {
   if (!w || O < 1 || Tt < 1 || I < 1 || Ipad < I) MI_FAIL(MI355_EINVAL, "pack_weights: bad args");
   dim3 grid(cdiv(Ipad, 32), cdiv(O, 32), Tt);

@@ -48,6 +48,7 @@ SIGNATURES = {
     'mi355_conv_wgrad_workspace': (_Z, [_D]),
     'mi355_conv_wgrad': (_I, [_D, _P, _P, _P, _I, _P, _Z, _P]),
     'mi355_pack_weights': (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    'mi355_pack_weights_batched': (_I, [_P, _I, _I, _I, _P]),
     'mi355_colsum_workspace': (_Z, [_L, _I]),
     'mi355_colsum': (_I, [_P, _P, _L, _I, _I, _I, _P, _Z, _P]),
     'mi355_bn_workspace': (_Z, [_L, _I]),

@@ -80,7 +80,40 @@ class _PackedWeights:
                 self.wt = torch.empty(O * T * Ipad, dtype=dtype, device=weight.device)
             ops.pack_weights_into(weight.detach(), self.wf, self.wt, O, T, I, Ipad, dtype)
             self.key = key
+            weight._mi_pack = (self, O, T, I, Ipad)        # lets the optimizer refresh all copies of a group in one launch
         return self.wf, self.wt
+
+
+_PACK_BATCHED = __import__('os').environ.get('MI355_PACK_BATCHED', '1') == '1'
+
+
+def repack_params(params, cache):
+    """Refresh the packed compute-dtype copies of every conv weight in `params` with ONE kernel (called by FusedSGD right
+    after its step, instead of one pack launch per conv at the next forward).  `cache`: a dict owned by the caller."""
+    if not _PACK_BATCHED:
+        return
+    ents = [(p, p._mi_pack) for p in params if getattr(p, '_mi_pack', None) is not None and p._mi_pack[0].wf is not None]
+    if not ents:
+        return
+    sig = tuple((p.data_ptr(), e[0].wf.data_ptr(), e[0].wt.data_ptr()) for p, e in ents)
+    if cache.get('sig') != sig:
+        if torch.cuda.is_current_stream_capturing():
+            return                                     # table not built yet: the convs repack lazily, as before
+        import numpy as np
+        rec = np.zeros(len(ents), dtype=[('w', '<u8'), ('wf', '<u8'), ('wt', '<u8'), ('O', '<i4'), ('T', '<i4'), ('I', '<i4'),
+                                         ('Ipad', '<i4'), ('blk0', '<i4'), ('pad', '<i4')])
+        blk = 0
+        for i, (p, (pk, O, T, I, Ipad)) in enumerate(ents):
+            rec[i] = (p.data_ptr(), pk.wf.data_ptr(), pk.wt.data_ptr(), O, T, I, Ipad, blk, 0)
+            blk += ((Ipad + 31) // 32) * ((O + 31) // 32) * T
+        cache['tab'] = torch.from_numpy(rec.view(np.uint8).copy()).to(ents[0][0].device)
+        cache['blocks'], cache['sig'] = blk, sig
+    dtype = ents[0][1][0].wf.dtype
+    if any(e[0].wf.dtype != dtype for _, e in ents):
+        return
+    ops.pack_weights_batched(cache['tab'], len(ents), cache['blocks'], dtype)
+    for p, (pk, O, T, I, Ipad) in ents:
+        pk.key = (_param_version(p), dtype, Ipad)
 
 
 def _chk_convform(weight):

@@ -152,6 +152,11 @@ def pack_weights(w_master, O, T, I, Ipad, dtype, want_f=True, want_t=True):
     return wf, wt
 
 
+def pack_weights_batched(table, nitems, total_blocks, dtype):
+    """table: uint8 device tensor holding `nitems` mi355_pack_item records."""
+    call('mi355_pack_weights_batched', ptr(table), int(nitems), int(total_blocks), dtype_code(dtype), stream_ptr())
+
+
 def pack_weights_into(w_master, wf, wt, O, T, I, Ipad, dtype):
     call('mi355_pack_weights', ptr(w_master), ptr(wf), ptr(wt), O, T, I, Ipad, dtype_code(dtype), stream_ptr())
 

@@ -11,7 +11,7 @@ from torch.optim import Optimizer
 
 import mi355 as _rt
 from . import ops
-from .nn import mark_grads_fresh
+from .nn import mark_grads_fresh, repack_params
 
 
 class FusedSGD(Optimizer):
@@ -109,6 +109,7 @@ class FusedSGD(Optimizer):
             ops.sgd_nesterov(f['P'], f['G'], f['M'], f['lr_dev'], g['momentum'], g['weight_decay'], g['nesterov'])
             for p in f['params']:
                 p._mi_epoch = getattr(p, '_mi_epoch', 0) + 1
+            repack_params(f['params'], f.setdefault('pack_cache', {}))     # packed conv copies: one launch per group
         return loss
 
     def load_state_dict(self, state_dict):

@@ -98,6 +98,10 @@ int mi355_conv_wgrad(const mi355_conv_desc* d, const void* x, const void* dy, fl
 /* fp32 master [O][T][I] -> packed `dtype` copies: wf [O][T][Ipad] (cast) and/or wt [Ipad][T][O] (transposed);
  * channels I..Ipad-1 are zero (the 3-channel stem is padded to one 16-byte chunk). */
 int mi355_pack_weights(const float* w, void* wf, void* wt, int O, int T, int I, int Ipad, int dtype, void* stream);
+/* The same for many weights in one launch (all convs of an optimizer group, right after its step).  items: DEVICE array;
+ * blk0 = first block of the item = sum over earlier items of ceil(Ipad/32)*ceil(O/32)*T; total_blocks = that sum over all. */
+typedef struct mi355_pack_item { const float* w; void* wf; void* wt; int O, T, I, Ipad, blk0, pad_; } mi355_pack_item;
+int mi355_pack_weights_batched(const mi355_pack_item* items_dev, int nitems, int total_blocks, int dtype, void* stream);
 /* dbias[C] (=|+=) column sums of dy[rows][C] (bias gradient of the biased head convs). */
 size_t mi355_colsum_workspace(long rows, int C);
 int mi355_colsum(const void* dy, float* out, long rows, int C, int dtype, int accumulate, void* ws,

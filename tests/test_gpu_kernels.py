@@ -483,3 +483,23 @@ def test_gemm_epilogue_bn_backward_reduction(gpu, dt, mode, case):
     sc = float(dga.abs().max()) + float(dba.abs().max()) + 1.0
     assert float((dga - dgb).abs().max()) <= 2e-5 * sc and float((dba - dbb).abs().max()) <= 2e-5 * sc
     assert float((dxa.float() - dxb.float()).abs().max()) <= (2e-2 if dt == 'bf16' else 1e-4) * (float(dxa.float().abs().max()) + 1e-6)
+
+
+@pytest.mark.parametrize('dt', ['f32', 'bf16'])
+def test_pack_weights_batched(gpu, dt):
+    """One launch packing several conv weights == the per-weight pack (incl. the padded 3-channel stem)."""
+    ops = _ops()
+    shapes = [(64, 49, 3, 8 if dt == 'bf16' else 4), (128, 9, 64, 64), (40, 1, 72, 72), (256, 16, 64, 64)]    # O, T, I, Ipad
+    ws = [randn(30 + i, O, T, I).to(gpu) for i, (O, T, I, Ip) in enumerate(shapes)]
+    ref = [ops.pack_weights(w, O, T, I, Ip, DT[dt]) for w, (O, T, I, Ip) in zip(ws, shapes)]
+    outs = [(torch.full_like(a, 3.0), torch.full_like(b, 3.0)) for a, b in ref]
+    rec = np.zeros(len(shapes), dtype=[('w', '<u8'), ('wf', '<u8'), ('wt', '<u8'), ('O', '<i4'), ('T', '<i4'), ('I', '<i4'),
+                                       ('Ipad', '<i4'), ('blk0', '<i4'), ('pad', '<i4')])
+    blk = 0
+    for i, ((O, T, I, Ip), w, (wf, wt)) in enumerate(zip(shapes, ws, outs)):
+        rec[i] = (w.data_ptr(), wf.data_ptr(), wt.data_ptr(), O, T, I, Ip, blk, 0)
+        blk += ((Ip + 31) // 32) * ((O + 31) // 32) * T
+    tab = torch.from_numpy(rec.view(np.uint8).copy()).to(gpu)
+    ops.pack_weights_batched(tab, len(shapes), blk, DT[dt])
+    for (a, b), (wf, wt) in zip(ref, outs):
+        assert torch.equal(a, wf) and torch.equal(b, wt)
