@@ -4,10 +4,11 @@
 // (bitwise reproducible; no atomics).  Slice partials stay slice-major: a channel-major layout makes the finalize
 // kernels 35 % faster but the scattered 4-byte partial writes cost the statistics kernels twice that (measured).
 #include "common.h"
+#include <stdlib.h>
 
 struct BnPlan { int cpr, TX, TY, colgroups, nslices, rows_per_slice; };
 
-static BnPlan bn_plan(long rows, int C, int CH) {
+static BnPlan bn_plan(long rows, int C, int CH, long slice_cap_override = 0) {
   BnPlan p; p.cpr = C / CH;
   p.TX = p.cpr < 256 ? p.cpr : 256;
   // TX must divide 256
@@ -15,17 +16,23 @@ static BnPlan bn_plan(long rows, int C, int CH) {
   p.TY = 256 / p.TX;
   p.colgroups = cdiv(p.cpr, p.TX);
   long want = rows / ((long)p.TY * 8); if (want < 1) want = 1;
-  long cap = 1024 / p.colgroups; if (cap < 1) cap = 1;
+  static const long slice_cap = getenv("MI355_BN_SLICES") ? atol(getenv("MI355_BN_SLICES")) : 1024;
+  long cap = (slice_cap_override ? slice_cap_override : slice_cap) / p.colgroups; if (cap < 1) cap = 1;
   if (want > cap) want = cap;
   long rps = (rows + want - 1) / want; rps = ((rps + p.TY - 1) / p.TY) * p.TY;
   p.rows_per_slice = (int)rps; p.nslices = (int)((rows + rps - 1) / rps);
   return p;
 }
 
+// the backward reduction (about 90 VGPRs, 5 blocks per CU) gets 1280 slices = one resident wave of blocks
+static long bwd_slices() { static const long v = getenv("MI355_BN_BWD_SLICES") ? atol(getenv("MI355_BN_BWD_SLICES")) : 1280; return v; }
 extern "C" size_t mi355_bn_workspace(long rows, int C) {
-  BnPlan p = bn_plan(rows, C, 4);  // fp32 chunking gives the larger plan
-  BnPlan q = bn_plan(rows, C, 8);
-  int ns = p.nslices > q.nslices ? p.nslices : q.nslices;
+  int ns = 0;
+  for (int ch = 4; ch <= 8; ch += 4) {     // fp32 / bf16 chunking, forward / backward plan: the largest
+    BnPlan p = bn_plan(rows, C, ch), q = bn_plan(rows, C, ch, bwd_slices());
+    if (p.nslices > ns) ns = p.nslices;
+    if (q.nslices > ns) ns = q.nslices;
+  }
   return ((size_t)ns * C * 3 + 4 * (size_t)C) * sizeof(float);
 }
 extern "C" size_t mi355_colsum_workspace(long rows, int C) { return mi355_bn_workspace(rows, C); }
@@ -305,9 +312,13 @@ static int bn_check(long rows, int C, int dtype, int* CH) {
   if (rows < 1 || C < 1 || C % *CH) MI_FAIL(MI355_EINVAL, "bn: C=%d must be a positive multiple of %d (rows=%ld)", C, *CH, rows);
   return 0;
 }
-static dim3 apply_grid(const BnPlan& p, long rows) {
+// grid = what is resident at once (256 CUs x blocks per CU at the kernel's register count): a second, partial wave of blocks
+// costs more than longer grid-stride loops (backward apply, 86 VGPRs -> 5 blocks per CU: 158 -> 148 us on 134 MB tensors)
+static dim3 apply_grid(const BnPlan& p, long rows, bool backward = false) {
   long gy = rows / ((long)p.TY * 4); if (gy < 1) gy = 1;
-  long cap = 2048 / p.colgroups; if (cap < 1) cap = 1;
+  static const long fwd_cap = getenv("MI355_BN_APPLY_CAP") ? atol(getenv("MI355_BN_APPLY_CAP")) : 2048;
+  static const long bwd_cap = getenv("MI355_BN_BWD_CAP") ? atol(getenv("MI355_BN_BWD_CAP")) : 1280;
+  long cap = (backward ? bwd_cap : fwd_cap) / p.colgroups; if (cap < 1) cap = 1;
   if (gy > cap) gy = cap;
   return dim3(p.colgroups, (unsigned)gy);
 }
@@ -380,14 +391,14 @@ extern "C" int mi355_bn_bwd(const void* dy, const void* x, const void* y, const 
   if (relu) relu = y ? 1 : 2;
   if (relu == 2 && !beta) MI_FAIL(MI355_EINVAL, "bn_bwd: relu without y needs beta");
   hipStream_t st = as_stream(stream);
-  BnPlan p = bn_plan(rows, C, CH);
+  BnPlan p = bn_plan(rows, C, CH, bwd_slices());
   float* partial = reinterpret_cast<float*>(ws);
   float* coeff = partial + (size_t)p.nslices * C * 3;   // 3*C floats (4*C reserved)
   dim3 g(p.colgroups, p.nslices);
   if (dtype == MI355_BF16) hipLaunchKernelGGL((bn_bwd_reduce_kernel<bf16_t, true>), g, dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)x, (const bf16_t*)y, save_mean, save_invstd, gamma, beta, partial, rows, C, p.TX, p.rows_per_slice, relu);
   else hipLaunchKernelGGL((bn_bwd_reduce_kernel<float, true>), g, dim3(256), 0, st, (const float*)dy, (const float*)x, (const float*)y, save_mean, save_invstd, gamma, beta, partial, rows, C, p.TX, p.rows_per_slice, relu);
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 4)), dim3(256), 0, st, partial, p.nslices, C, 1.0f / (float)rows, gamma, save_invstd, dgamma, dbeta, accumulate, coeff);
-  dim3 ga = apply_grid(p, rows);
+  dim3 ga = apply_grid(p, rows, true);
   if (dtype == MI355_BF16) hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, ga, dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)x, (const bf16_t*)y, save_mean, save_invstd, coeff, beta, (bf16_t*)dx, (bf16_t*)dresidual, rows, C, p.TX, relu);
   else hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, ga, dim3(256), 0, st, (const float*)dy, (const float*)x, (const float*)y, save_mean, save_invstd, coeff, beta, (float*)dx, (float*)dresidual, rows, C, p.TX, relu);
   MI_CHECK_LAUNCH("bn_bwd");
@@ -407,7 +418,7 @@ extern "C" int mi355_bn_bwd_partials(const void* dy, const void* x, const void* 
   hipStream_t st = as_stream(stream);
   BnPlan p = bn_plan(rows, C, CH);
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 4)), dim3(256), 0, st, partial, nslices, C, 1.0f / (float)rows, gamma, save_invstd, dgamma, dbeta, accumulate, coeff);
-  dim3 ga = apply_grid(p, rows);
+  dim3 ga = apply_grid(p, rows, true);
   if (dtype == MI355_BF16) hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, ga, dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)x, (const bf16_t*)y, save_mean, save_invstd, coeff, beta, (bf16_t*)dx, (bf16_t*)dresidual, rows, C, p.TX, relu);
   else hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, ga, dim3(256), 0, st, (const float*)dy, (const float*)x, (const float*)y, save_mean, save_invstd, coeff, beta, (float*)dx, (float*)dresidual, rows, C, p.TX, relu);
   MI_CHECK_LAUNCH("bn_bwd_partials");
