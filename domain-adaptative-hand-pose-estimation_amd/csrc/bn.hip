@@ -24,8 +24,8 @@ static BnPlan bn_plan(long rows, int C, int CH, long slice_cap_override = 0) {
   return p;
 }
 
-// the backward reduction (about 90 VGPRs, 5 blocks per CU) gets 1280 slices = one resident wave of blocks
-static long bwd_slices() { static const long v = getenv("MI355_BN_BWD_SLICES") ? atol(getenv("MI355_BN_BWD_SLICES")) : 1280; return v; }
+// the backward reduction (two rows per trip, 134 VGPRs, 3 blocks per CU) gets 768 slices = one resident wave of blocks
+static long bwd_slices() { static const long v = getenv("MI355_BN_BWD_SLICES") ? atol(getenv("MI355_BN_BWD_SLICES")) : 768; return v; }
 extern "C" size_t mi355_bn_workspace(long rows, int C) {
   int ns = 0;
   for (int ch = 4; ch <= 8; ch += 4) {     // fp32 / bf16 chunking, forward / backward plan: the largest
@@ -194,24 +194,39 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
       for (int e = 0; e < CH; ++e) { sc[e] = gamma[chunk * CH + e] * is[e]; sft[e] = beta[chunk * CH + e] - mu[e] * sc[e]; }
     }
   }
-  if (colok)
-    for (long r = r0 + ty; r < r1; r += TY) {
-      const size_t off = (size_t)r * C + (size_t)chunk * CH;
-      float g[CH]; Chunk<T>::load(dy + off, g);
-      if (relu == 1) { float o[CH]; Chunk<T>::load(y + off, o);
+  auto fold = [&](float (&g)[CH], const float (&v)[CH], const float (&o)[CH]) {
+    if (relu == 1) {
 #pragma unroll
-        for (int e = 0; e < CH; ++e) g[e] = o[e] > 0.f ? g[e] : 0.f; }
-      if (XHAT) { float v[CH]; Chunk<T>::load(x + off, v);
-        if (relu == 2) {
+      for (int e = 0; e < CH; ++e) g[e] = o[e] > 0.f ? g[e] : 0.f; }
+    if (XHAT) {
+      if (relu == 2) {
 #pragma unroll
-          for (int e = 0; e < CH; ++e) g[e] = (v[e] * sc[e] + sft[e]) > 0.f ? g[e] : 0.f; }
+        for (int e = 0; e < CH; ++e) g[e] = (v[e] * sc[e] + sft[e]) > 0.f ? g[e] : 0.f; }
 #pragma unroll
-        for (int e = 0; e < CH; ++e) { s1[e] += g[e]; s2[e] += g[e] * ((v[e] - mu[e]) * is[e]); }
-      } else {
+      for (int e = 0; e < CH; ++e) { s1[e] += g[e]; s2[e] += g[e] * ((v[e] - mu[e]) * is[e]); }
+    } else {
 #pragma unroll
-        for (int e = 0; e < CH; ++e) s1[e] += g[e];
-      }
+      for (int e = 0; e < CH; ++e) s1[e] += g[e];
     }
+  };
+  if (colok) {
+    long r = r0 + ty;
+    for (; r + TY < r1; r += 2 * TY) {          // two rows per trip: twice the loads in flight
+      const size_t off0 = (size_t)r * C + (size_t)chunk * CH, off1 = off0 + (size_t)TY * C;
+      float g0[CH], v0[CH], o0[CH], g1[CH], v1[CH], o1[CH];
+      Chunk<T>::load(dy + off0, g0); Chunk<T>::load(dy + off1, g1);
+      if (XHAT) { Chunk<T>::load(x + off0, v0); Chunk<T>::load(x + off1, v1); }
+      if (relu == 1) { Chunk<T>::load(y + off0, o0); Chunk<T>::load(y + off1, o1); }
+      fold(g0, v0, o0); fold(g1, v1, o1);
+    }
+    if (r < r1) {
+      const size_t off = (size_t)r * C + (size_t)chunk * CH;
+      float g[CH], v[CH], o[CH]; Chunk<T>::load(dy + off, g);
+      if (XHAT) Chunk<T>::load(x + off, v);
+      if (relu == 1) Chunk<T>::load(y + off, o);
+      fold(g, v, o);
+    }
+  }
 #pragma unroll
   for (int e = 0; e < CH; ++e) { sh[threadIdx.x * CH + e] = s1[e]; sh[256 * CH + threadIdx.x * CH + e] = s2[e]; }
   __syncthreads();
@@ -274,10 +289,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
     k0[e] = coeff[c]; k1[e] = coeff[C + c]; k2[e] = coeff[2 * C + c]; mu[e] = mean[c]; is[e] = invstd[c];
     sh[e] = (relu == 2) ? beta[c] - mu[e] * k0[e] : 0.f;      // k0 = gamma*invstd = forward scale
   }
-  for (long r = (long)blockIdx.y * TY + ty; r < rows; r += (long)gridDim.y * TY) {
-    const size_t off = (size_t)r * C + (size_t)chunk * CH;
-    float g[CH], v[CH]; Chunk<T>::load(dy + off, g); Chunk<T>::load(x + off, v);
-    if (relu == 1) { float o[CH]; Chunk<T>::load(y + off, o);
+  auto finish = [&](size_t off, float (&g)[CH], float (&v)[CH], const float (&o)[CH]) {
+    if (relu == 1) {
 #pragma unroll
       for (int e = 0; e < CH; ++e) g[e] = o[e] > 0.f ? g[e] : 0.f; }
     else if (relu == 2) {
@@ -287,6 +300,23 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
 #pragma unroll
     for (int e = 0; e < CH; ++e) v[e] = k0[e] * (g[e] - k1[e] - (v[e] - mu[e]) * is[e] * k2[e]);
     Chunk<T>::store(dx + off, v);
+  };
+  // two rows per trip: twice the loads in flight per wave (the kernel is latency-, not issue-bound)
+  const long stride = (long)gridDim.y * TY;
+  long r = (long)blockIdx.y * TY + ty;
+  for (; r + stride < rows; r += 2 * stride) {
+    const size_t off0 = (size_t)r * C + (size_t)chunk * CH, off1 = (size_t)(r + stride) * C + (size_t)chunk * CH;
+    float g0[CH], v0[CH], o0[CH], g1[CH], v1[CH], o1[CH];
+    Chunk<T>::load(dy + off0, g0); Chunk<T>::load(x + off0, v0);
+    Chunk<T>::load(dy + off1, g1); Chunk<T>::load(x + off1, v1);
+    if (relu == 1) { Chunk<T>::load(y + off0, o0); Chunk<T>::load(y + off1, o1); }
+    finish(off0, g0, v0, o0); finish(off1, g1, v1, o1);
+  }
+  if (r < rows) {
+    const size_t off = (size_t)r * C + (size_t)chunk * CH;
+    float g[CH], v[CH], o[CH]; Chunk<T>::load(dy + off, g); Chunk<T>::load(x + off, v);
+    if (relu == 1) Chunk<T>::load(y + off, o);
+    finish(off, g, v, o);
   }
 }
 
@@ -313,11 +343,11 @@ static int bn_check(long rows, int C, int dtype, int* CH) {
   return 0;
 }
 // grid = what is resident at once (256 CUs x blocks per CU at the kernel's register count): a second, partial wave of blocks
-// costs more than longer grid-stride loops (backward apply, 86 VGPRs -> 5 blocks per CU: 158 -> 148 us on 134 MB tensors)
+// costs more than longer grid-stride loops (backward apply, two rows per trip, 122 VGPRs -> 4 blocks per CU)
 static dim3 apply_grid(const BnPlan& p, long rows, bool backward = false) {
   long gy = rows / ((long)p.TY * 4); if (gy < 1) gy = 1;
   static const long fwd_cap = getenv("MI355_BN_APPLY_CAP") ? atol(getenv("MI355_BN_APPLY_CAP")) : 2048;
-  static const long bwd_cap = getenv("MI355_BN_BWD_CAP") ? atol(getenv("MI355_BN_BWD_CAP")) : 1280;
+  static const long bwd_cap = getenv("MI355_BN_BWD_CAP") ? atol(getenv("MI355_BN_BWD_CAP")) : 1024;
   long cap = (backward ? bwd_cap : fwd_cap) / p.colgroups; if (cap < 1) cap = 1;
   if (gy > cap) gy = cap;
   return dim3(p.colgroups, (unsigned)gy);
