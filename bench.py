@@ -192,10 +192,19 @@ def main():
         step.graphs = None
         n_prof = min(args.steps, 5)
         ops.prof_reset(); ops.prof_enable(True)
-        for _ in range(n_prof):
-            step.run(batch); tick()
+        # eager launches are host-bound here (the Python layer cannot feed a 40 ms iteration in 40 ms), and an event pair
+        # around a launch the GPU had to wait for would also time the wait: so every iteration is enqueued behind an idle
+        # spin as long as the host needs to enqueue it -- the GPU then runs launch after launch, events back to back
         torch.cuda.synchronize()
+        t_q = time.perf_counter(); step.run(batch); tick(); host_ms = (time.perf_counter() - t_q) * 1e3
+        torch.cuda.synchronize()
+        ops.prof_reset()
+        for _ in range(n_prof):
+            ops.spin_us(int(min(1.5 * host_ms + 20.0, 1500.0) * 1e3))
+            step.run(batch); tick()
+            torch.cuda.synchronize()
         ops.prof_enable(False)
+        log('roofline pass: host needs %.0f ms to enqueue one eager iteration' % host_ms)
     if not args.no_roofline and rank == 0:
         ms, launches, flops, abytes = ops.prof_read()
         log('roofline pass done')
@@ -206,12 +215,13 @@ def main():
         algo = flops - stem_excess
         ach = algo / (ms * 1e-3) / 1e12
         peak = PEAK_TFLOPS[args.dtype]
-        roof = {'bound': 'mfma', 'kernel': 'gather_gemm_kernel + wgrad_gemm_kernel (implicit-GEMM conv family)',
+        roof = {'bound': 'mfma', 'kernel': 'gather_gemm_kernel + wgrad_gemm_kernel + wgrad_kw_kernel (implicit-GEMM conv family)',
                 'achieved': round(ach, 2), 'peak': peak, 'unit': 'TFLOP/s', 'frac': round(ach / peak, 4),
                 'traffic': pmc_traffic(args), 'traffic_unit': 'bytes per launch (rocprofv3 PMC: 2*FETCH_SIZE + WRITE_SIZE, separate passes)',
                 'algorithmic_bytes_per_launch': round(abytes / launches), 'launches_per_step': launches // n_prof,
                 'algorithmic_gflop_per_launch': round(algo / launches / 1e9, 3),
                 'avg_launch_us': round(ms * 1e3 / launches, 2),
+                'event_dispatch_overhead_us': round(ops.prof_event_overhead_us(256), 2),
                 'conv_ms_per_step': round(ms / n_prof, 3)}
     if world > 1:
         dist.barrier()

@@ -52,3 +52,37 @@ extern "C" int mi355_prof_read(double* total_ms, long* launches, double* flops, 
   if (total_ms) *total_ms = ms; if (launches) *launches = p.launches; if (flops) *flops = p.flops; if (bytes) *bytes = p.bytes;
   return MI355_OK;
 }
+
+// ---- a timed idle spin on the stream: lets a measurement enqueue its launches behind a known delay, so that the
+// events bracketing each launch are processed back to back on the GPU instead of waiting for the host (bench.py)
+__global__ void spin_kernel(long ticks) {
+  const long t0 = (long)wall_clock64();                 // constant 100 MHz counter
+  while ((long)wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+}
+extern "C" int mi355_spin_us(long us, void* stream) {
+  if (us < 0 || us > 2000000) MI_FAIL(MI355_EINVAL, "spin_us: 0..2e6 us");
+  hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(1), 0, as_stream(stream), us * 100);
+  MI_CHECK_LAUNCH("spin_us");
+  return MI355_OK;
+}
+
+// What an event pair reads around a kernel that does nothing: the dispatch latency every event-timed launch carries on
+// top of its own duration (rocprofv3 kernel durations do not contain it).  The n launches are queued behind a spin.
+extern "C" int mi355_prof_event_overhead_us(int n, void* stream, double* us) {
+  if (n < 1 || n > 4096 || !us) MI_FAIL(MI355_EINVAL, "prof_event_overhead_us: bad args");
+  hipStream_t st = as_stream(stream);
+  std::vector<hipEvent_t> ev(2 * n);
+  for (auto& e : ev) if (hipEventCreate(&e) != hipSuccess) MI_FAIL(MI355_ELAUNCH, "event create failed");
+  hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(1), 0, st, 20000L * 100);      // 20 ms head start for the host
+  for (int i = 0; i < n; ++i) {
+    (void)hipEventRecord(ev[2 * i], st);
+    hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(1), 0, st, 0L);
+    (void)hipEventRecord(ev[2 * i + 1], st);
+  }
+  if (hipStreamSynchronize(st) != hipSuccess) MI_FAIL(MI355_ELAUNCH, "sync failed");
+  double tot = 0;
+  for (int i = 0; i < n; ++i) { float t = 0; (void)hipEventElapsedTime(&t, ev[2 * i], ev[2 * i + 1]); tot += t; }
+  for (auto& e : ev) (void)hipEventDestroy(e);
+  *us = tot * 1e3 / n;
+  return MI355_OK;
+}

@@ -380,6 +380,16 @@ def cast_f32(src, dst):
 
 
 # ---------------------------------------------------------------- kernel timer (bench.py roofline)
+def spin_us(us):
+    call('mi355_spin_us', int(us), stream_ptr())
+
+
+def prof_event_overhead_us(n=256):
+    us = ctypes.c_double(0)
+    call('mi355_prof_event_overhead_us', int(n), stream_ptr(), ctypes.byref(us))
+    return us.value
+
+
 def prof_enable(on):
     call('mi355_prof_enable', int(on))
 

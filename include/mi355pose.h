@@ -236,6 +236,10 @@ int mi355_cast_f32(const float* in, void* out, long n, int dtype, void* stream);
  * When enabled, every launch of the MFMA conv family is bracketed by hipEvents on its stream.
  * mi355_prof_read synchronises the recorded events and returns totals since the last reset. */
 int mi355_prof_enable(int on);
+/* idle spin of `us` microseconds on the stream (measurement aid: queue launches behind it so the GPU never waits for the host) */
+int mi355_spin_us(long us, void* stream);
+/* mean reading of an event pair around an empty kernel (the dispatch latency contained in every event-timed launch) */
+int mi355_prof_event_overhead_us(int n, void* stream, double* us);
 int mi355_prof_reset(void);
 int mi355_prof_read(double* total_ms, long* launches, double* flops, double* algorithmic_bytes);
 
