@@ -315,19 +315,27 @@ _PW_MFMA = _os.environ.get('MI355_PW_MFMA', '1') != '0'      # A/B switch: MFMA 
 
 
 class _CastCopy:
-    """compute-dtype copy of a small fp32 master ([K][C] / [C][K] point-wise weights), refreshed on change."""
+    """compute-dtype copy of a small fp32 master ([K][C] / [C][K] point-wise weights), refreshed on change.
+    transposed=True keeps the [K][C] copy of a [C][K] master (torch glue: the matrix is 21 x 256)."""
 
-    def __init__(self):
+    def __init__(self, transposed=False):
         self.key, self.buf = None, None
+        self.transposed = transposed
 
     def get(self, w, dtype):
-        if dtype == torch.float32:
+        if dtype == torch.float32 and not self.transposed:
             return w.detach()
         key = (_param_version(w), dtype)
         if key != self.key:
-            if self.buf is None or self.buf.device != w.device:
-                self.buf = torch.empty(w.numel(), dtype=dtype, device=w.device)
-            ops.cast_f32(w.detach(), self.buf)
+            if self.transposed:
+                w2 = w.detach().reshape(w.shape[0], -1)
+                if self.buf is None or self.buf.device != w.device or self.buf.dtype != dtype:
+                    self.buf = torch.empty(w2.shape[1], w2.shape[0], dtype=dtype, device=w.device)
+                self.buf.copy_(w2.t())
+            else:
+                if self.buf is None or self.buf.device != w.device:
+                    self.buf = torch.empty(w.numel(), dtype=dtype, device=w.device)
+                ops.cast_f32(w.detach(), self.buf)
             self.key = key
         return self.buf
 
@@ -387,10 +395,11 @@ class _PwK2CFn(torch.autograd.Function):
     """1x1 conv K heat-map -> C features (+ fused residual add)."""
 
     @staticmethod
-    def forward(ctx, hm, weight, bias, residual, dtype):
+    def forward(ctx, hm, weight, bias, residual, dtype, mod=None):
         C = weight.shape[0]
         out = ops.pw_k2c(hm, weight.detach(), bias, C, dtype, residual=residual)
         ctx.has_bias = bias is not None
+        ctx.mod = mod
         ctx.save_for_backward(hm, weight, bias)
         return out
 
@@ -400,7 +409,12 @@ class _PwK2CFn(torch.autograd.Function):
         dout = _as_grad(dout, dout.dtype)
         dhm = None
         if ctx.needs_input_grad[0]:     # dhm[k] = sum_c dout[c] * w[c][k] -> c2k with the [C][K] weight
-            dhm = ops.pw_c2k(dout, weight.detach(), None, hm.shape[1], w_transposed=True)
+            C, K = weight.shape[0], hm.shape[1]
+            if _PW_MFMA and ctx.mod is not None and C >= 64 and (C & (C - 1)) == 0:
+                # the heat-map gradient is itself a C -> K 1x1 conv with the transposed weight: MFMA kernel, NCHW fp32 out
+                dhm = ops.conv1x1_heatmap(dout, ctx.mod._cast_t.get(weight, dout.dtype), None, K)
+            else:
+                dhm = ops.pw_c2k(dout, weight.detach(), None, K, w_transposed=True)
         if ctx.needs_input_grad[1]:
             g, acc = grad_slot(weight)
             if _PW_MFMA:
@@ -411,7 +425,7 @@ class _PwK2CFn(torch.autograd.Function):
             g, acc = grad_slot(bias)
             ops.colsum(dout, g, acc)
         dres = dout if ctx.needs_input_grad[3] else None
-        return dhm, None, None, dres, None
+        return dhm, None, None, dres, None, None
 
 
 # ---------------------------------------------------------------- modules
@@ -429,6 +443,7 @@ class Conv2d(nn.Module):
         self.bias = nn.Parameter(torch.empty(out_channels)) if bias else None
         self._packed = _PackedWeights()
         self._cast = _CastCopy()
+        self._cast_t = _CastCopy(transposed=True)
         self._stem_tmp = None
         self._last_partial = None
         self._in_bn_src = None
@@ -502,7 +517,7 @@ class Conv2d(nn.Module):
                 x = x.float().contiguous()
             if not x.is_cuda:
                 raise Mi355Error('mi355 layers need CUDA/HIP tensors; there is no CPU fallback')
-            return _PwK2CFn.apply(x, self.weight, self.bias, residual, dtype)
+            return _PwK2CFn.apply(x, self.weight, self.bias, residual, dtype, self)
         if x.shape[1] == self.in_channels and self.in_channels != self._cin_pad(dtype):
             x = ops.to_nhwc(x if (x.dtype == torch.float32 and x.is_contiguous()) else x.float().contiguous(),
                             dtype, self._cin_pad(dtype))
