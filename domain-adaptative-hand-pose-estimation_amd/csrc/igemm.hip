@@ -943,6 +943,9 @@ static int dispatch_gather(GatherArgs& a, hipStream_t st) {
     // LDS-DMA ring for K-heavy layers (>= 16 K-tiles): +9..12 % on the 3x3 / 4x4 convs, but -15 % on short-K 1x1 convs
     // (2 blocks/CU instead of 3), so those keep the register-staged form.  MI355_DMA=0 disables, =2 forces (tests).
     else if ((dma_mode == 2 && a.Nout > 64) || (dma_mode == 1 && t128 >= 512 && kavg >= 128)) launch_gather<T, 128, 128, false, 2, 2, false, true>(a, st);
+    // short-K 1x1 convs at large M are all prologue / epilogue and HBM-bound: more, smaller blocks in flight win
+    // (64->256 @64x64: 54.5 -> 47.0 us, 256->256: 79.6 -> 68.9 us)
+    else if (t128 >= 512 && kavg <= 32 && sizeof(T) == 2) launch_gather<T, 64, 128, false>(a, st);
     else if (t128 >= 512) launch_gather<T, 128, 128, false>(a, st);   // (128x256 tile with 8 waves measured slower: 687 vs 755 TFLOP/s)
     else if (cdiv(Mtot, 64L) * cdiv(a.Nout, 128) >= 512) launch_gather<T, 64, 128, false>(a, st);
     else launch_gather<T, 64, 64, false>(a, st);
