@@ -131,22 +131,43 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gather_gemm_kernel(const Gathe
   // this form 723, prefetch distance 2 with two register sets (184 VGPRs -> 2 blocks/CU) 616.
   uint4 ra0[RA], rb0[RB];
   const int cmask = (1 << p.cshift) - 1;
-  auto load_tile = [&](int kt, uint4 (&ra)[RA], uint4 (&rb)[RB]) {
-    int q, tap, cc; bool okq;
-    if (SMALL_C) { q = kt * 8 + lc; okq = q < pkchunks; tap = okq ? (q >> p.cshift) : 0; cc = (q & cmask) * CH; }
-    else { int q0 = kt * 8; tap = q0 >> p.cshift; cc = ((q0 & cmask) + lc) * CH; okq = true; }
-    const Tap tp = ptaps[tap];
-    const int koff = (int)tp.widx * p.Ci + cc;
+  // element offset of every row's window origin: the per-tap part of an A address is then one scalar (dy*Wi+dx)*Ci --
+  // no per-row integer multiplies inside the K loop (v_mul_lo_u32 is quarter rate)
+  int pix0[RA];
 #pragma unroll
-    for (int i = 0; i < RA; ++i) {
-      int iy = iy0[i] + tp.dy, ix = ix0[i] + tp.dx;
-      bool ok = okq && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
-      ra[i] = buf_load16(rsA, ok ? ((abase[i] + iy * p.Wi + ix) * p.Ci + cc) * (int)sizeof(T) : OOB_OFF);
-    }
+  for (int i = 0; i < RA; ++i) pix0[i] = iy0[i] >= 0 ? (abase[i] + iy0[i] * p.Wi + ix0[i]) * p.Ci : 0;
+  auto tap_of = [&](int kt) -> Tap { return ptaps[(kt * 8) >> p.cshift]; };     // (large-channel path: one tap per K-tile)
+  auto load_tile = [&](int kt, const Tap tpu, uint4 (&ra)[RA], uint4 (&rb)[RB]) {
+    if constexpr (SMALL_C) {
+      const int q = kt * 8 + lc; const bool okq = q < pkchunks; const int tap = okq ? (q >> p.cshift) : 0; const int cc = (q & cmask) * CH;
+      const Tap tp = ptaps[tap];
+      const int koff = (int)tp.widx * p.Ci + cc;
 #pragma unroll
-    for (int i = 0; i < RB; ++i) {
-      int n = n0 + lr + RPP * i;
-      rb[i] = buf_load16(rsB, (okq && n < p.Nout) ? (n * p.ldb + koff) * (int)sizeof(T) : OOB_OFF);
+      for (int i = 0; i < RA; ++i) {
+        int iy = iy0[i] + tp.dy, ix = ix0[i] + tp.dx;
+        bool ok = okq && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
+        ra[i] = buf_load16(rsA, ok ? ((abase[i] + iy * p.Wi + ix) * p.Ci + cc) * (int)sizeof(T) : OOB_OFF);
+      }
+#pragma unroll
+      for (int i = 0; i < RB; ++i) {
+        int n = n0 + lr + RPP * i;
+        rb[i] = buf_load16(rsB, (okq && n < p.Nout) ? (n * p.ldb + koff) * (int)sizeof(T) : OOB_OFF);
+      }
+    } else {
+      const int cc = (((kt * 8) & cmask) + lc) * CH;
+      const int toff = ((int)tpu.dy * p.Wi + (int)tpu.dx) * p.Ci + cc;
+      const int koff = (int)tpu.widx * p.Ci + cc;
+#pragma unroll
+      for (int i = 0; i < RA; ++i) {
+        const int iy = iy0[i] + tpu.dy, ix = ix0[i] + tpu.dx;
+        const bool ok = (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
+        ra[i] = buf_load16(rsA, ok ? (pix0[i] + toff) * (int)sizeof(T) : OOB_OFF);
+      }
+#pragma unroll
+      for (int i = 0; i < RB; ++i) {
+        int n = n0 + lr + RPP * i;
+        rb[i] = buf_load16(rsB, n < p.Nout ? (n * p.ldb + koff) * (int)sizeof(T) : OOB_OFF);
+      }
     }
   };
   // LDS-DMA issue of K-tile kt into ring stage `stage`: lane (row lr, physical chunk lc) fetches the logical chunk
@@ -158,6 +179,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gather_gemm_kernel(const Gathe
     const int cc = ((q0 & cmask) + lcs) * CH;
     const Tap tp = ptaps[tap];
     const int koff = (int)tp.widx * p.Ci + cc;
+    const int toff = ((int)tp.dy * p.Wi + (int)tp.dx) * p.Ci + cc;
 #if defined(__HIP_DEVICE_COMPILE__)    // (the host pass must still be able to emit the kernel stub)
     typedef __attribute__((address_space(3))) void* ldsp;
     char* sa = smem + stage * SM::kStage + wave_u * 1024;
@@ -167,7 +189,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gather_gemm_kernel(const Gathe
       int iy = iy0[i] + tp.dy, ix = ix0[i] + tp.dx;
       bool ok = (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (ldsp)(sa + i * RPP * 128), 16,
-                                               ok ? ((abase[i] + iy * p.Wi + ix) * p.Ci + cc) * (int)sizeof(T) : OOB_OFF, 0, 0, 0);
+                                               ok ? (pix0[i] + toff) * (int)sizeof(T) : OOB_OFF, 0, 0, 0);
     }
 #pragma unroll
     for (int i = 0; i < RB; ++i) {
@@ -244,10 +266,13 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gather_gemm_kernel(const Gathe
   } else {
     // (two K-tiles in flight for the small tiles -- 64x128 and below have the registers -- measured: no gain on the
     //  latency-bound mid-size layers, occupancy 5 -> 3; per-K-step issue cost, not prefetch depth, bounds them)
-    load_tile(0, ra0, rb0);
+    load_tile(0, tap_of(0), ra0, rb0);
+    Tap tpn = tap_of(nk > 1 ? 1 : 0);                      // the tap word of tile kt+1 is fetched one iteration early
     for (int kt = 0; kt < nk; ++kt) {
+      const Tap tpu = tpn;
+      if (kt + 2 < nk) tpn = tap_of(kt + 2);
       __syncthreads(); store_tile(ra0, rb0); __syncthreads();
-      if (kt + 1 < nk) load_tile(kt + 1, ra0, rb0);
+      if (kt + 1 < nk) load_tile(kt + 1, tpu, ra0, rb0);
       __builtin_amdgcn_s_setprio(1);
       compute();
       __builtin_amdgcn_s_setprio(0);
