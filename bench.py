@@ -184,6 +184,22 @@ def main():
     log('timed region done: %.2f ms/step' % ms_per_step)
     losses = {k: float(step.out[k]) for k in ('loss_s', 'loss_gf', 'loss_gt')}
 
+    # ---- forward-only throughput of the test.py path (eval-mode BatchNorm, main head only, arg-max decode), SURVEY 8(d)
+    model.eval()
+    from utils.keypoint_detection import get_max_preds_device
+    with torch.no_grad():
+        for _ in range(3):
+            get_max_preds_device(model(batch['x_t']))
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        n_eval = 10
+        for _ in range(n_eval):
+            get_max_preds_device(model(batch['x_t']))
+        torch.cuda.synchronize()
+        eval_ms = (time.perf_counter() - t0) / n_eval * 1e3
+    model.train()
+    log('eval path: %.2f ms per batch of %d' % (eval_ms, B))
+
     # ---- roofline of the dominant kernel family (MFMA implicit-GEMM conv: gather + wgrad kernels), rank 0:
     # the same K steps again, eagerly, every conv launch bracketed by hipEvents on its stream.
     roof = None
@@ -239,6 +255,7 @@ def main():
                        'arch': args.arch, 'image_size': S, 'per_gpu_batch': B, 'global_batch': B * world,
                        'parallelism': 'dp%d' % world, 'hip_graphs': use_graph},
             'model_passes_per_s': round(3 * B * world / (ms_per_step * 1e-3), 2),
+            'eval_images_per_s_per_gpu': round(B / (eval_ms * 1e-3), 1),
             'losses_last_step': losses,
         }
         if F is not None:

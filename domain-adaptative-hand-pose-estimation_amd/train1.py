@@ -29,7 +29,7 @@ from mi355.optim import FusedSGD
 from uda.model.loss import JointsKLLoss
 from uda.model.pose_resnet2 import Upsampling, PoseResNet
 from uda.model.regda_7 import PoseResNetx9 as RegDAPoseResNetx1, PoseResNetx10 as RegDAPoseResNetx2
-from utils.data import ForeverDataIterator
+from utils.data import ForeverDataIterator, DevicePrefetcher
 from utils.keypoint_detection import accuracy
 from utils.logger import CompleteLogger
 from utils.meter import AverageMeter, ProgressMeter, AverageMeterDict
@@ -81,6 +81,8 @@ def main(args):
     print("Source train:", len(train_source_loader)); print("Target train:", len(train_target_loader))
     print("Source test:", len(val_source_loader)); print("Target test:", len(val_target_loader))
     train_source_iter, train_target_iter = ForeverDataIterator(train_source_loader), ForeverDataIterator(train_target_loader)
+    # host -> HBM copies of the next batch overlap the current step (pinned, double-buffered, side stream)
+    train_source_iter, train_target_iter = DevicePrefetcher(train_source_iter, device), DevicePrefetcher(train_target_iter, device)
 
     # model (+ the frozen EMA copy the reference builds and checkpoints, train1.py:102-128)
     backbone = models.__dict__[args.arch](pretrained=True)

@@ -130,3 +130,22 @@ def test_batch_of_one_and_frozen_parameters(gpu):
     y_adv3.sum().backward()
     got = {n for n, p in m.named_parameters() if p.grad is not None}
     assert got and all(n.startswith('head_adv3.') for n in got)
+
+
+def test_device_prefetcher_stages_batches_in_order(gpu):
+    """Pinned double-buffered host->HBM staging (utils.data.DevicePrefetcher): every batch arrives intact, in order, on the
+    device, for pinned and pageable host tensors alike; non-tensor items pass through; the source's end ends the iterator."""
+    from utils.data import DevicePrefetcher, ForeverDataIterator
+    torch.manual_seed(0)
+    host = [(torch.randn(4, 3, 32, 32), torch.rand(4, 21, 8, 8).pin_memory(), torch.ones(4, 21, 1) * i, {'i': i}) for i in range(7)]
+    got = list(DevicePrefetcher(iter(host), gpu))
+    assert len(got) == 7
+    for (x, l, w, meta), (gx, gl, gw, gmeta) in zip(host, got):
+        assert gx.is_cuda and gl.is_cuda and gw.is_cuda and gmeta is meta
+        assert torch.equal(gx.cpu(), x) and torch.equal(gl.cpu(), l) and torch.equal(gw.cpu(), w)
+    # with the endless iterator of the training loop: batches keep coming, the staging slots are reused
+    it = DevicePrefetcher(ForeverDataIterator(host[:3]), gpu)
+    seq = [int(next(it)[2][0, 0, 0]) for _ in range(8)]
+    assert seq == [0, 1, 2, 0, 1, 2, 0, 1]
+    with pytest.raises(ValueError):
+        DevicePrefetcher(iter(host), 'cpu')
