@@ -14,6 +14,8 @@ Differences from the reference loop that do not change any result (documented in
 Data parallelism: one process per GPU; the flat gradient buffers of the optimizers about to step are
 all-reduced (mean) over the default process group between the backward and the optimizer kernels.
 """
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -32,6 +34,56 @@ def _allreduce_mean(bufs):
         else:
             dist.all_reduce(b, op=dist.ReduceOp.SUM)
             b.div_(ws)
+
+
+def _distributed():
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+
+class _OverlapReducer:
+    """Gradient mean of one backward pass, started piecewise while the pass is still running.
+
+    Tensor hooks on the outputs of the neck and of the ResNet stages tell when everything *behind* that tensor has finished
+    its backward: the flat gradient range of those parameters is then all-reduced asynchronously (the collective's
+    stream waits for the kernels enqueued so far and runs beside the rest of the backward).  ``finish()`` reduces whatever
+    no hook covered (always the stem / layer1 range, everything in the very first iteration when the optimizers are not
+    flat yet) and waits for all collectives.  The result equals one all-reduce per buffer; only the timing differs."""
+
+    def __init__(self, step, keys):
+        self.step, self.keys = step, tuple(keys)
+        self.works, self.covered = [], {}
+        self.avg = dist.get_backend() == 'nccl'
+
+    def _launch(self, G, lo, hi):
+        t = G[lo:hi]
+        w = dist.all_reduce(t, op=dist.ReduceOp.AVG if self.avg else dist.ReduceOp.SUM, async_op=True)
+        self.works.append((w, t))
+        self.covered.setdefault(G.data_ptr(), []).append((lo, hi))
+
+    def stage_done(self, stage):
+        """Called from a gradient hook: the parameters of `stage` (a key of DAStep._stage_params) have their gradients."""
+        for key, params in self.step._stage_params.get(stage, ()):
+            if key not in self.keys:
+                continue
+            opt = self.step.opt[key]
+            rng = opt.flat_range(params) if hasattr(opt, 'flat_range') else None
+            if rng is not None:
+                self._launch(*rng)
+
+    def finish(self):
+        for G in self.step._grads(self.keys):
+            done = sorted(self.covered.get(G.data_ptr(), []))
+            pos = 0
+            for lo, hi in done + [(G.numel(), G.numel())]:
+                if lo > pos:
+                    self._launch(G, pos, lo)
+                pos = max(pos, hi)
+        ws = dist.get_world_size()
+        for w, t in self.works:
+            w.wait()
+            if not self.avg:
+                t.div_(ws)
+        self.works = []
 
 
 def broadcast_module(module, src=0):
@@ -58,6 +110,54 @@ class DAStep:
         self.graphs = None
         self.out = {}
         self._adv_params = [p for n in ('head_adv', 'head_adv2', 'head_adv3') for p in getattr(model, n).parameters()]
+        self._reducer = None
+        self._stage_params = {}
+        self.overlap = os.environ.get('MI355_OVERLAP_ALLREDUCE', '1') == '1'
+        self._install_stage_hooks()
+
+    # ------------------------------------------------------------------ all-reduce overlapped with the backward
+    def _install_stage_hooks(self):
+        """Forward hooks that put a gradient hook on the output of the neck and of every ResNet stage.  When such a
+        gradient arrives, the modules behind that tensor have finished their backward (see _OverlapReducer)."""
+        m = self.model
+        bb, up = getattr(m, 'backbone', None), getattr(m, 'upsampling', None)
+        if bb is None or up is None or not all(hasattr(bb, n) for n in ('layer1', 'layer2', 'layer3', 'layer4', 'maxpool')):
+            return
+        heads = [(k, list(getattr(m, n).parameters())) for k, n in (('h', 'head'), ('h_adv', 'head_adv'), ('h_adv2', 'head_adv2'),
+                                                                    ('h_adv3', 'head_adv3')) if hasattr(m, n)]
+        self._stage_params = {                         # gradient of <tensor> ready  ->  these parameters are done
+            'neck_out': heads,
+            'layer4_out': [('f', list(up.parameters()))],
+            'layer3_out': [('f', list(bb.layer4.parameters()))],
+            'layer2_out': [('f', list(bb.layer3.parameters()))],
+            'layer1_out': [('f', list(bb.layer2.parameters()))],
+            'pool_out': [('f', list(bb.layer1.parameters()))],
+        }
+
+        def fwd_hook(stage):
+            def hook(mod, inp, out):
+                if torch.is_tensor(out) and out.requires_grad:
+                    out.register_hook(lambda g, s=stage: self._on_stage_grad(s))
+            return hook
+        for stage, mod in (('neck_out', up), ('layer4_out', bb.layer4), ('layer3_out', bb.layer3), ('layer2_out', bb.layer2),
+                           ('layer1_out', bb.layer1), ('pool_out', bb.maxpool)):
+            mod.register_forward_hook(fwd_hook(stage))
+
+    def _on_stage_grad(self, stage):
+        if self._reducer is not None:
+            self._reducer.stage_done(stage)
+
+    def _begin_reduce(self, keys):
+        """Arm the overlapped reducer for the backward about to run (eager, more than one rank, no side-stream wgrads)."""
+        self._reducer = _OverlapReducer(self, keys) if (self.overlap and _distributed() and not _rt.SIDE_WGRAD and
+                                                         not torch.cuda.is_current_stream_capturing()) else None
+
+    def _end_reduce(self, keys):
+        r, self._reducer = self._reducer, None
+        if r is not None:
+            r.finish()
+        else:
+            _allreduce_mean(self._grads(keys))
 
     # ------------------------------------------------------------------ the three steps (fwd+bwd, then update)
     def _fwdbwd_A(self, b):
@@ -164,14 +264,16 @@ class DAStep:
         if self.graphs is not None:
             return self.replay(batch)
         self.model.train()
+        self._begin_reduce(('f', 'h', 'h_adv', 'h_adv2', 'h_adv3'))
         self._fwdbwd_A(batch)
-        _allreduce_mean(self._grads(('f', 'h', 'h_adv', 'h_adv2', 'h_adv3')))
+        self._end_reduce(('f', 'h', 'h_adv', 'h_adv2', 'h_adv3'))
         self._update_A()
-        self._fwdbwd_B(batch)
+        self._fwdbwd_B(batch)                    # (heads only: nothing to overlap with)
         _allreduce_mean(self._grads(('h_adv', 'h_adv2', 'h_adv3')))
         self._update_B()
+        self._begin_reduce(('f',))
         self._fwdbwd_C(batch)
-        _allreduce_mean(self._grads(('f',)))
+        self._end_reduce(('f',))
         self._update_C()
         self._accuracy(batch)
         self.model.step()

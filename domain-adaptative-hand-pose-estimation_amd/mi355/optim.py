@@ -64,9 +64,29 @@ class FusedSGD(Optimizer):
                 st['momentum_buffer'] = mv
                 p._mi_epoch = getattr(p, '_mi_epoch', 0) + 1     # packed copies must be rebuilt (storage moved)
             lr_dev = torch.zeros((), dtype=torch.float32, device=dev)
-            flat.append(dict(P=P, G=G, M=M, params=ps, lr_dev=lr_dev, gi=gi))
+            flat.append(dict(P=P, G=G, M=M, params=ps, lr_dev=lr_dev, gi=gi,
+                             offs={id(p): (o, (p.numel() + 3) // 4 * 4) for p, o in zip(ps, offs)}))
         self._flat = flat
         self.sync_lr(force=True)
+
+    def flat_range(self, params):
+        """(G buffer, lo, hi) covering `params` -- which must be neighbours inside one flat group -- or None when the
+        optimizer is not flat yet / the parameters own no gradient.  Used to all-reduce a finished part of the backward
+        while the rest is still running."""
+        if self._flat is None:
+            return None
+        ids = [id(p) for p in params]
+        for f in self._flat:
+            if f is None:
+                continue
+            hit = [f['offs'][i] for i in ids if i in f['offs']]
+            if hit:
+                lo = min(o for o, _ in hit)
+                hi = max(o + n for o, n in hit)
+                if sum(n for _, n in hit) != hi - lo:
+                    return None                  # not contiguous: leave it to the final pass
+                return f['G'], lo, hi
+        return None
 
     def flat_grads(self):
         """The contiguous gradient buffers (one per group) — what the data-parallel all-reduce operates on."""

@@ -1,0 +1,71 @@
+"""Two data-parallel ranks sharing the one GPU of the test box (gloo collectives on device tensors): the gradient exchange
+that is started piecewise from gradient hooks while the backward is still running must give exactly the parameters of the
+plain exchange after the backward, identical on both ranks.  (RCCL needs one GPU per rank; the driver's 8-GPU run covers it.)"""
+import os
+import socket
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _worker(rank, world, port, overlap, q):
+    from conftest import PKG  # noqa: F401  (package source root on sys.path in the spawned process)
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), MI355_OVERLAP_ALLREDUCE='1' if overlap else '0')
+    torch.cuda.set_device(0)
+    dev = torch.device('cuda', 0)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    import mi355
+    import mi355.da_step as ds
+    import uda.model as models
+    from uda.model.pose_resnet2 import Upsampling
+    from uda.model.regda_7 import PoseResNetx9
+    from utils.synthetic import make_batch
+    mi355.load(); mi355.set_compute_dtype('f32')
+    torch.manual_seed(1)
+    bb = models.resnet18(pretrained=False)
+    model = PoseResNetx9(bb, Upsampling(bb.out_features), 256, 21, num_head_layers=2, finetune=True).to(dev)
+    ds.broadcast_module(model, 0)
+    step, opts, scheds = ds.build_training(model, heatmap_size=32)
+    batch = make_batch(2, 128, 32, seed=1 + rank, device=dev)
+    pieces = []
+    orig = ds._OverlapReducer._launch
+    ds._OverlapReducer._launch = lambda self, G, lo, hi: (pieces.append((lo, hi)), orig(self, G, lo, hi))[1]
+    for _ in range(3):
+        step.run(batch)
+        for s in scheds.values():
+            s.step()
+    torch.cuda.synchronize()
+    cs = [float(p.detach().double().abs().sum()) for p in model.parameters()]
+    q.put((rank, cs, len(pieces)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _run(overlap):
+    world, port = 2, _free_port()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, overlap, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=240) for _ in range(world)), key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    return res
+
+
+def test_overlapped_gradient_exchange_equals_plain_exchange(gpu):
+    on, off = _run(True), _run(False)
+    assert on[0][1] == on[1][1], 'ranks diverged with the overlapped exchange'
+    assert off[0][1] == off[1][1]
+    assert on[0][1] == off[0][1], 'overlapped and plain exchange disagree'
+    assert on[0][2] > 10 and off[0][2] == 0          # the pieces really were launched from the hooks
