@@ -163,6 +163,17 @@ def main():
         step.run(batch); tick()
     log('eager warm-up done')
     use_graph = (not args.no_graph) and (world == 1 or args.graph)
+    if world > 1 and not use_graph and not args.no_graph and (args.backend == 'nccl' or os.environ.get('MI355_BENCH_ADAPT_ANY') == '1'):
+        # eager launches keep the gradient exchange overlapped with the backward, but only pay off while the host can feed
+        # the GPU: if enqueueing an iteration takes (nearly) as long as running it on ANY rank, every rank replays graphs
+        # instead (collectives between the graphs).  The decision is all-reduced so that all ranks take the same path.
+        torch.cuda.synchronize()
+        t_a = time.perf_counter(); step.run(batch); tick(); t_host = time.perf_counter() - t_a
+        torch.cuda.synchronize(); t_gpu = time.perf_counter() - t_a
+        r = torch.tensor([t_host / max(t_gpu, 1e-9)], device=dev)
+        dist.all_reduce(r, op=dist.ReduceOp.MAX)
+        use_graph = float(r) > 0.95
+        log('multi-rank launch mode: host/GPU time ratio %.2f -> %s' % (float(r), 'graph replay' if use_graph else 'eager + overlapped all-reduce'))
     if use_graph:
         step.capture(batch, warmup=0)
         log('graphs captured')
