@@ -180,6 +180,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gather_gemm_kernel(const Gathe
     const Tap tp = ptaps[tap];
     const int koff = (int)tp.widx * p.Ci + cc;
     const int toff = ((int)tp.dy * p.Wi + (int)tp.dx) * p.Ci + cc;
+    (void)koff; (void)toff; (void)wave_u;   // (only used in the device pass below)
 #if defined(__HIP_DEVICE_COMPILE__)    // (the host pass must still be able to emit the kernel stub)
     typedef __attribute__((address_space(3))) void* ldsp;
     char* sa = smem + stage * SM::kStage + wave_u * 1024;

@@ -195,7 +195,9 @@ class _ConvFn(torch.autograd.Function):
 class _ConvSkipFn(torch.autograd.Function):
     """conv(x) together with an alias of x for the parallel branch of a residual block (identity / downsample input).
     In backward the conv's input gradient is added onto the branch's gradient inside the dgrad epilogue, which replaces
-    the separate element-wise add autograd would run at the fork (one read+write pass of the block input less)."""
+    the separate element-wise add autograd would run at the fork (one read+write pass of the block input less).
+    Contract: the branch gradient is accumulated IN PLACE, so the branch's consumer must hand back a buffer of its own
+    (true for BatchNorm2d's residual input and for conv / deconv input gradients -- the only users in the model)."""
 
     @staticmethod
     def forward(ctx, x, weight, mod):
@@ -626,7 +628,8 @@ class MaxPool2d(nn.Module):
 def link_conv_bn(module):
     """Mark every conv / deconv child that is directly followed (in registration order) by a BatchNorm2d child: in training
     mode such a conv computes the BatchNorm statistics of its output in its epilogue.  Only a hint -- the BatchNorm uses the
-    partials solely when they arrive attached to the very tensor it normalises."""
+    partials solely when they arrive attached to the very tensor it normalises (``y._mi_bn_partial``); a conv output that is
+    modified in place before it reaches the BatchNorm would carry stale statistics -- the model never does that."""
     kids = list(module.children())
     for a, b in zip(kids, kids[1:]):
         if isinstance(a, (Conv2d, ConvTranspose2d)) and isinstance(b, BatchNorm2d):
