@@ -27,6 +27,7 @@ struct GatherArgs {
   int accumulate;
   int nphase, ntn, ntiles;     // ntiles = nphase * max_phase(ntm) * ntn
   int hw;                      // heat-map output mode: pixels per image
+  int lw;                      // KW3: log2(min(W, 128))
   unsigned a_bytes, b_bytes;
   size_t stat_bytes;           // (host) capacity of stat_partial
   int stat_slices;             // (host) slices the launch writes: nphase * ntm, 0 when the statistics were not fused
@@ -68,9 +69,10 @@ template <> struct MmaTraits<bf16_t> { static constexpr int BK = 64; static cons
 template <> struct MmaTraits<float> { static constexpr int BK = 32; static constexpr int CH = 4; };
 
 #define GATHER_STAGES 1     // one LDS stage: the pipeline depth lives in registers (see the K loop)
-template <typename T, int BM, int BN, int STAGES = 1>
+template <typename T, int BM, int BN, int STAGES = 1, bool KW3 = false>
 struct GatherSmem {
-  static constexpr int kStage = (BM + BN) * 128;
+  static constexpr int kARows = KW3 ? BM + 4 * (BM / 8) + 4 : BM;        // KW3: segmented A image with spare rows (see the kernel)
+  static constexpr int kStage = (kARows + BN) * 128;
   static constexpr int kOutStride = BN * (int)sizeof(T) + 16;
   static constexpr int kOut = BM * kOutStride;
   static constexpr int kBytes = (STAGES * kStage > kOut ? STAGES * kStage : kOut) + BM * 4;
@@ -82,13 +84,20 @@ struct GatherSmem {
 //      zeros) into a 2-stage ring: no staging registers, no ds_write, one barrier per K-tile.
 // EPI: epilogue extras, compiled separately so the plain kernel keeps its register budget (3 blocks per CU):
 //      0 plain, 1 + BatchNorm statistics of the output, 2 + BatchNorm-backward reduction of the output.
-template <typename T, int BM, int BN, bool SMALL_C, int WGM = 2, int WGN = 2, bool HM_OUT = false, bool DMA = false, int EPI = 0>
+// KW3: 3x3 / unit-stride convs (forward and input gradient).  The three taps of a kernel row read the same pixels shifted by
+//      -1 / 0 / +1, so ONE staged A tile per (kernel row, 64-channel chunk) serves three K sub-steps (three B tiles): a third
+//      fewer bytes through L1 and LDS per MFMA.  The LDS A image keeps every run of min(W,128) pixels in a segment of its
+//      own with spare zero rows between segments, so a shifted fragment read sees zeros exactly at the image border
+//      (same construction as wgrad_kw_kernel).
+template <typename T, int BM, int BN, bool SMALL_C, int WGM = 2, int WGN = 2, bool HM_OUT = false, bool DMA = false, int EPI = 0,
+          bool KW3 = false>
 __global__ __launch_bounds__(64 * WGM * WGN) void gather_gemm_kernel(const GatherArgs p) {
   constexpr int CH = MmaTraits<T>::CH;
   constexpr int NTHR = 64 * WGM * WGN, RPP = NTHR / 8;      // rows staged per pass (8 lanes = one 128-byte row)
   constexpr int WM = BM / WGM, WN = BN / WGN, MT = WM / 32, NT = WN / 32;
   constexpr int RA = BM / RPP, RB = BN / RPP;
-  using SM = GatherSmem<T, BM, BN, DMA ? 2 : 1>;
+  using SM = GatherSmem<T, BM, BN, DMA ? 2 : 1, KW3>;
+  static_assert(!KW3 || (!DMA && !SMALL_C && !HM_OUT && sizeof(T) == 2), "KW3 is a bf16 variant of the plain large-channel kernel");
   static_assert(!DMA || !SMALL_C, "the LDS-DMA pipeline is built for the large-channel path");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   int* row_off = reinterpret_cast<int*>(smem + SM::kBytes - BM * 4);
@@ -201,7 +210,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gather_gemm_kernel(const Gathe
 #endif
   };
   char* as = smem;
-  char* bs = smem + BM * 128;
+  char* bs = smem + SM::kARows * 128;
   auto store_tile = [&](const uint4 (&ra)[RA], const uint4 (&rb)[RB]) {
 #pragma unroll
     for (int i = 0; i < RA; ++i) *reinterpret_cast<uint4*>(as + swz128(lr + RPP * i, lc)) = ra[i];
@@ -251,7 +260,76 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gather_gemm_kernel(const Gathe
   };
 
   const int nk = (pkchunks + 7) >> 3;
-  if constexpr (DMA) {
+  if constexpr (KW3) {
+    // sub-step ks = (group g, kw), group g = (kernel row kh, channel chunk): tap index kh*3 + kw, channels chunk*64 ..
+    const int nchunk = p.Ci >> 6, nsub = 9 * nchunk;
+    for (int i = t; i < SM::kARows * 8; i += NTHR) reinterpret_cast<uint4*>(as)[i] = make_uint4(0, 0, 0, 0);
+    int simg[RA];                                         // LDS byte offset of this thread's A rows in the segmented image
+#pragma unroll
+    for (int i = 0; i < RA; ++i) { const int r = lr + RPP * i; simg[i] = swz128(r + 2 + 4 * (r >> p.lw), lc); }
+    int rimg[MT];                                         // image row of this lane's fragment rows
+#pragma unroll
+    for (int i = 0; i < MT; ++i) { const int q = wm0 + i * 32 + r31; rimg[i] = q + 2 + 4 * (q >> p.lw); }
+    auto load_a = [&](int g, uint4 (&ra)[RA]) {
+      const int kh = g / nchunk, chunk = g - kh * nchunk;
+      const int dyv = ptaps[kh * 3].dy;
+      const int toff = dyv * p.Wi * p.Ci + chunk * 64 + lc * CH;
+#pragma unroll
+      for (int i = 0; i < RA; ++i) {
+        const bool ok = (unsigned)(iy0[i] + dyv) < (unsigned)p.Hi;
+        ra[i] = buf_load16(rsA, ok ? (pix0[i] + toff) * (int)sizeof(T) : OOB_OFF);
+      }
+    };
+    auto load_b = [&](int ks, uint4 (&rb)[RB]) {
+      const int g = ks / 3, kw = ks - g * 3;
+      const int kh = g / nchunk, chunk = g - kh * nchunk;
+      const int koff = (int)ptaps[kh * 3 + kw].widx * p.Ci + chunk * 64 + lc * CH;
+#pragma unroll
+      for (int i = 0; i < RB; ++i) {
+        const int n = n0 + lr + RPP * i;
+        rb[i] = buf_load16(rsB, n < p.Nout ? (n * p.ldb + koff) * (int)sizeof(T) : OOB_OFF);
+      }
+    };
+    auto compute_kw = [&](int dxv) {
+      int arow[MT], axor[MT];
+#pragma unroll
+      for (int i = 0; i < MT; ++i) { const int r = rimg[i] + dxv; arow[i] = r * 128; axor[i] = (r >> 1) & 7; }
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        bf16x8_t a[MT], b[NT];
+#pragma unroll
+        for (int i = 0; i < MT; ++i) a[i] = *reinterpret_cast<const bf16x8_t*>(as + arow[i] + (((2 * s + hi) ^ axor[i]) << 4));
+#pragma unroll
+        for (int j = 0; j < NT; ++j) b[j] = *reinterpret_cast<const bf16x8_t*>(bs + swz128(wn0 + j * 32 + r31, 2 * s + hi));
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[j], a[i], acc[i][j], 0, 0, 0);
+      }
+    };
+    load_a(0, ra0);
+    load_b(0, rb0);
+    int kw = 0, g = 0;
+    for (int ks = 0; ks < nsub; ++ks) {
+      const int dxv = ptaps[(g / nchunk) * 3 + kw].dx;
+      __syncthreads();                                    // sub-step ks-1 fully multiplied
+      if (kw == 0) {
+#pragma unroll
+        for (int i = 0; i < RA; ++i) *reinterpret_cast<uint4*>(as + simg[i]) = ra0[i];
+      }
+#pragma unroll
+      for (int i = 0; i < RB; ++i) *reinterpret_cast<uint4*>(bs + swz128(lr + RPP * i, lc)) = rb0[i];
+      __syncthreads();
+      if (ks + 1 < nsub) {
+        load_b(ks + 1, rb0);
+        if (kw == 2) load_a(g + 1, ra0);                  // the next group's A tile travels during this group's last sub-step
+      }
+      __builtin_amdgcn_s_setprio(1);
+      compute_kw(dxv);
+      __builtin_amdgcn_s_setprio(0);
+      if (++kw == 3) { kw = 0; ++g; }
+    }
+  } else if constexpr (DMA) {
     dma_tile(0, 0);
     for (int kt = 0; kt < nk; ++kt) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -892,16 +970,16 @@ __global__ void zero_fill_kernel(uint4* __restrict__ p, size_t n16) {
 // ------------------------------------------------------------------------------------ host side
 static int ilog2_exact(int v) { int s = 0; while ((1 << s) < v) ++s; return ((1 << s) == v) ? s : -1; }
 
-template <typename T, int BM, int BN, bool SMALL_C, int WGM, int WGN, bool HM_OUT, bool DMA, int EPI>
+template <typename T, int BM, int BN, bool SMALL_C, int WGM, int WGN, bool HM_OUT, bool DMA, int EPI, bool KW3 = false>
 static void launch_gather_epi(const GatherArgs& a, hipStream_t st) {
-  constexpr int smem = GatherSmem<T, BM, BN, DMA ? 2 : 1>::kBytes;
-  auto kern = gather_gemm_kernel<T, BM, BN, SMALL_C, WGM, WGN, HM_OUT, DMA, EPI>;
+  constexpr int smem = GatherSmem<T, BM, BN, DMA ? 2 : 1, KW3>::kBytes;
+  auto kern = gather_gemm_kernel<T, BM, BN, SMALL_C, WGM, WGN, HM_OUT, DMA, EPI, KW3>;
   static bool attr_set = false;   // raise the dynamic-LDS cap once per instantiation
   if (!attr_set) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem); attr_set = true; }
   hipLaunchKernelGGL(kern, dim3(a.ntiles), dim3(64 * WGM * WGN), smem, st, a);
 }
 
-template <typename T, int BM, int BN, bool SMALL_C, int WGM = 2, int WGN = 2, bool HM_OUT = false, bool DMA = false>
+template <typename T, int BM, int BN, bool SMALL_C, int WGM = 2, int WGN = 2, bool HM_OUT = false, bool DMA = false, bool KW3 = false>
 static void launch_gather(GatherArgs& a, hipStream_t st) {
   a.ntn = cdiv(a.Nout, BN);
   int mx = 0;
@@ -923,10 +1001,10 @@ static void launch_gather(GatherArgs& a, hipStream_t st) {
   constexpr bool EXTRAS = !HM_OUT && BM <= 128;     // the epilogue variants exist for the regular tiles only
   if (!EXTRAS && (a.stat_partial || a.bnb_partial)) { a.stat_partial = nullptr; a.bnb_partial = nullptr; a.stat_slices = 0; }
   if constexpr (EXTRAS) {
-    if (a.bnb_partial) { launch_gather_epi<T, BM, BN, SMALL_C, WGM, WGN, HM_OUT, DMA, 2>(a, st); return; }
-    if (a.stat_partial) { launch_gather_epi<T, BM, BN, SMALL_C, WGM, WGN, HM_OUT, DMA, 1>(a, st); return; }
+    if (a.bnb_partial) { launch_gather_epi<T, BM, BN, SMALL_C, WGM, WGN, HM_OUT, DMA, 2>(a, st); return; }     // (EPI 2 has no KW3 build)
+    if (a.stat_partial) { launch_gather_epi<T, BM, BN, SMALL_C, WGM, WGN, HM_OUT, DMA, 1, KW3>(a, st); return; }
   }
-  launch_gather_epi<T, BM, BN, SMALL_C, WGM, WGN, HM_OUT, DMA, 0>(a, st);
+  launch_gather_epi<T, BM, BN, SMALL_C, WGM, WGN, HM_OUT, DMA, 0, KW3>(a, st);
 }
 
 template <typename T>
@@ -963,11 +1041,25 @@ static int dispatch_gather(GatherArgs& a, hipStream_t st) {
   else if (force == 3) launch_gather<T, 64, 64, false>(a, st);
   else {
     const long t128 = cdiv(Mtot, 128L) * cdiv(a.Nout, 128);
+    // 3x3 / unit stride / same-size maps of a power-of-two width <= 128: the A-tile-sharing variant (see KW3 above)
+    static const int kw3_on = getenv("MI355_KW3") ? atoi(getenv("MI355_KW3")) : 1;
+    bool kw3 = kw3_on && sizeof(T) == 2 && a.nphase == 1 && a.ph[0].ntaps == 9 && a.in_sx == 1 && a.in_sy == 1 && a.out_sx == 1 &&
+               a.out_sy == 1 && a.ph[0].OWp == a.Wi && a.ph[0].OHp == a.Hi && a.Wo == a.Wi && a.Ho == a.Hi && a.Wi >= 8 &&
+               a.Wi <= 128 && ilog2_exact(a.Wi) >= 0 && a.Nout > 64 && a.Ci % 64 == 0 && !a.bnb_partial;
+    for (int g = 0; g < 3 && kw3; ++g) {
+      const Tap* tp = a.taps + a.ph[0].tap0 + 3 * g;
+      int seen = 0;
+      for (int k = 0; k < 3; ++k) { if (tp[k].dy != tp[0].dy || tp[k].dx < -1 || tp[k].dx > 1) kw3 = false; else seen |= 1 << (tp[k].dx + 1); }
+      if (seen != 7 || tp[0].dy < -1 || tp[0].dy > 1) kw3 = false;
+    }
+    if (kw3) a.lw = ilog2_exact(a.Wi);
     if (a.Nout <= 64) {
       if (cdiv(Mtot, 128L) >= 512) launch_gather<T, 128, 64, false>(a, st); else launch_gather<T, 64, 64, false>(a, st);
     } else if (sizeof(T) == 2 && getenv("MI355_T256") && a.Nout % 256 == 0 && cdiv(Mtot, 256L) * (a.Nout / 256) >= 256) launch_gather<T, 256, 256, false, 2, 4>(a, st);
     // LDS-DMA ring for K-heavy layers (>= 16 K-tiles): +9..12 % on the 3x3 / 4x4 convs, but -15 % on short-K 1x1 convs
     // (2 blocks/CU instead of 3), so those keep the register-staged form.  MI355_DMA=0 disables, =2 forces (tests).
+    // (measured: 334 -> 310 us forward, 324 -> 312 us dgrad on 256->256 @64x64; at 1024 tiles the LDS-DMA ring still wins)
+    else if (kw3 && (t128 >= 2048 || kw3_on == 2)) { if constexpr (sizeof(T) == 2) launch_gather<T, 128, 128, false, 2, 2, false, false, true>(a, st); }
     else if ((dma_mode == 2 && a.Nout > 64) || (dma_mode == 1 && t128 >= 512 && kavg >= 128)) launch_gather<T, 128, 128, false, 2, 2, false, true>(a, st);
     // short-K 1x1 convs at large M are all prologue / epilogue and HBM-bound: more, smaller blocks in flight win
     // (64->256 @64x64: 54.5 -> 47.0 us, 256->256: 79.6 -> 68.9 us)
