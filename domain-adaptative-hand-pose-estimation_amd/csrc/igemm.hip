@@ -91,7 +91,7 @@ struct GatherSmem {
 //      (same construction as wgrad_kw_kernel).
 template <typename T, int BM, int BN, bool SMALL_C, int WGM = 2, int WGN = 2, bool HM_OUT = false, bool DMA = false, int EPI = 0,
           bool KW3 = false>
-__global__ __launch_bounds__(64 * WGM * WGN) void gather_gemm_kernel(const GatherArgs p) {
+__global__ __launch_bounds__(64 * WGM * WGN, (KW3 && BM == 256) ? 2 : 1) void gather_gemm_kernel(const GatherArgs p) {
   constexpr int CH = MmaTraits<T>::CH;
   constexpr int NTHR = 64 * WGM * WGN, RPP = NTHR / 8;      // rows staged per pass (8 lanes = one 128-byte row)
   constexpr int WM = BM / WGM, WN = BN / WGN, MT = WM / 32, NT = WN / 32;
@@ -1059,6 +1059,8 @@ static int dispatch_gather(GatherArgs& a, hipStream_t st) {
     // LDS-DMA ring for K-heavy layers (>= 16 K-tiles): +9..12 % on the 3x3 / 4x4 convs, but -15 % on short-K 1x1 convs
     // (2 blocks/CU instead of 3), so those keep the register-staged form.  MI355_DMA=0 disables, =2 forces (tests).
     // (measured: 334 -> 310 us forward, 324 -> 312 us dgrad on 256->256 @64x64; at 1024 tiles the LDS-DMA ring still wins)
+    // 256x128 macro tile (128 accumulators per wave, 2 blocks/CU, 0.21 KB of L1 traffic per MFMA): 313 -> 302 us on the 64x64 layers
+    else if (kw3 && t128 >= 4096 && kw3_on != 2 && kw3_on != 4) { if constexpr (sizeof(T) == 2) launch_gather<T, 256, 128, false, 2, 2, false, false, true>(a, st); }
     else if (kw3 && (t128 >= 2048 || kw3_on == 2)) { if constexpr (sizeof(T) == 2) launch_gather<T, 128, 128, false, 2, 2, false, false, true>(a, st); }
     else if ((dma_mode == 2 && a.Nout > 64) || (dma_mode == 1 && t128 >= 512 && kavg >= 128)) launch_gather<T, 128, 128, false, 2, 2, false, true>(a, st);
     // short-K 1x1 convs at large M are all prologue / epilogue and HBM-bound: more, smaller blocks in flight win

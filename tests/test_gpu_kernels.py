@@ -56,6 +56,7 @@ CONV_CASES = [
     (1, 64, 20, 64, 128, 3, 1, 1),    # W = 64: one image row per tile, H not a power of two
     (1, 64, 6, 128, 64, 3, 1, 1),     # W = 128: half rows with halo pixels fetched from the neighbours
     (32, 64, 64, 64, 256, 3, 1, 1),   # 2048 output tiles: the shared-A-tile (KW3) forward / dgrad kernel is chosen by default
+    (64, 64, 64, 64, 256, 3, 1, 1),   # 4096 output tiles: its 256x128 macro-tile build
 ]
 
 
