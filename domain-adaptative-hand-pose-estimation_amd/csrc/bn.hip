@@ -136,6 +136,55 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
   scale_shift[c] = sc; scale_shift[C + c] = b - mean * sc;
 }
 
+// Many slices (statistics fused into a conv epilogue: one per 128-row tile, up to thousands): one 256-thread block per
+// channel instead of one wave.  Thread t folds slices t, t+256, ..., then the shuffle tree per wave and the four waves in
+// wave order -- again a fixed order.
+__global__ __launch_bounds__(256) void bn_finalize_wide_kernel(const float* __restrict__ partial, int nslices, int C, const float* __restrict__ gamma,
+                                        const float* __restrict__ beta, float* running_mean, float* running_var,
+                                        int64_t* nbt, float* save_mean, float* save_invstd, float* scale_shift, float eps,
+                                        float momentum, int repeats) {
+  __shared__ float red[4][3];
+  const int c = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  if (c == 0 && t == 0 && nbt) *nbt += repeats;
+  const float g = gamma[c], b = beta[c];
+  float rm = running_mean ? running_mean[c] : 0.f, rv = running_var ? running_var[c] : 0.f;
+  float n = 0.f, mean = 0.f, m2 = 0.f;
+  for (int base = 0; base < nslices; base += 2048) {
+    float qn[8], qm[8], qv[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int s = base + t + 256 * j;
+      if (s < nslices) { const float* q = partial + ((size_t)s * C + c) * 3; qn[j] = q[0]; qm[j] = q[1]; qv[j] = q[2]; }
+      else { qn[j] = 0.f; qm[j] = 0.f; qv[j] = 0.f; }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) chan_combine(n, mean, m2, qn[j], qm[j], qv[j]);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float nb = __shfl_down(n, o, 64), mb = __shfl_down(mean, o, 64), vb = __shfl_down(m2, o, 64);
+    chan_combine(n, mean, m2, nb, mb, vb);
+  }
+  if (lane == 0) { red[wave][0] = n; red[wave][1] = mean; red[wave][2] = m2; }
+  __syncthreads();
+  if (t != 0) return;
+  n = red[0][0]; mean = red[0][1]; m2 = red[0][2];
+#pragma unroll
+  for (int w = 1; w < 4; ++w) chan_combine(n, mean, m2, red[w][0], red[w][1], red[w][2]);
+  const float var = m2 / n;
+  const float invstd = 1.0f / sqrtf(var + eps);
+  save_mean[c] = mean; save_invstd[c] = invstd;
+  const float uvar = n > 1.f ? m2 / (n - 1.f) : var;
+  for (int r = 0; r < repeats; ++r) {
+    rm = (1.f - momentum) * rm + momentum * mean;
+    rv = (1.f - momentum) * rv + momentum * uvar;
+  }
+  if (running_mean && repeats > 0) running_mean[c] = rm;
+  if (running_var && repeats > 0) running_var[c] = rv;
+  const float sc = g * invstd;
+  scale_shift[c] = sc; scale_shift[C + c] = b - mean * sc;
+}
+
 template <typename T, bool EVAL>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, const T* __restrict__ res, T* __restrict__ y,
                                                         const float* __restrict__ scale_shift, const float* __restrict__ gamma,
@@ -388,7 +437,9 @@ extern "C" int mi355_bn_train_fwd_partials(const void* x, const void* residual, 
   if (!partial || nslices < 1 || !scale_shift) MI_FAIL(MI355_EINVAL, "bn_train_fwd_partials: partial / scale_shift missing");
   hipStream_t st = as_stream(stream);
   BnPlan p = bn_plan(rows, C, CH);
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 4)), dim3(256), 0, st, partial, nslices, C, gamma, beta, running_mean, running_var, nbt, save_mean, save_invstd, scale_shift, eps, momentum, stat_updates);
+  static const int wide_min = getenv("MI355_BN_WIDE_FINALIZE") ? atoi(getenv("MI355_BN_WIDE_FINALIZE")) : 512;
+  if (nslices >= wide_min) hipLaunchKernelGGL(bn_finalize_wide_kernel, dim3(C), dim3(256), 0, st, partial, nslices, C, gamma, beta, running_mean, running_var, nbt, save_mean, save_invstd, scale_shift, eps, momentum, stat_updates);
+  else hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 4)), dim3(256), 0, st, partial, nslices, C, gamma, beta, running_mean, running_var, nbt, save_mean, save_invstd, scale_shift, eps, momentum, stat_updates);
   dim3 ga = apply_grid(p, rows);
   const float* nf = nullptr;
   if (dtype == MI355_BF16) hipLaunchKernelGGL((bn_apply_kernel<bf16_t, false>), ga, dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)residual, (bf16_t*)y, (const float*)scale_shift, nf, nf, nf, nf, eps, rows, C, p.TX, relu);

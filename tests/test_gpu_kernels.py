@@ -125,6 +125,7 @@ STAT_CASES = [
     ('conv', 2, 3, 32, 32, 64, 7, 2, 3),       # stem (padded input channels, small-C kernel variant)
     ('conv', 1, 64, 9, 13, 64, 3, 1, 1),       # ragged: partial row tiles
     ('conv', 6, 64, 40, 40, 128, 1, 1, 0),     # 9600 rows: 128-row tiles
+    ('conv', 20, 64, 64, 64, 128, 1, 1, 0),    # 81920 rows: >= 640 slices -> the block-per-channel finalize kernel
     ('deconv', 2, 256, 16, 16, 64, 4, 2, 1),   # four output phases in one launch
 ]
 
