@@ -506,3 +506,23 @@ def test_pack_weights_batched(gpu, dt):
     ops.pack_weights_batched(tab, len(shapes), blk, DT[dt])
     for (a, b), (wf, wt) in zip(ref, outs):
         assert torch.equal(a, wf) and torch.equal(b, wt)
+
+
+def test_fused_statistics_fall_back_when_phases_are_uneven(gpu):
+    """A transposed conv onto an odd-sized map has output phases of different tile counts: the launch declines to fuse the
+    statistics (nslices = 0 -> None) and still produces the plain result; BatchNorm then runs its own statistics pass."""
+    ops = _ops()
+    N, Ci, H, W, Co, k, s, p = 1, 64, 17, 17, 64, 3, 2, 1          # conv-form: input 17x17 -> output 9x9; deconv output = 17x17
+    desc = ops.make_desc(N, H, W, Ci, Co, k, k, s, p, torch.float32)
+    w = randn(2, Co, Ci, k, k, scale=0.05)
+    wf, wt = ops.pack_weights(w.permute(0, 2, 3, 1).contiguous().to(gpu), Co, k * k, Ci, Ci, torch.float32)
+    x = _nhwc(randn(1, N, Co, desc.Ho, desc.Wo), 'f32', gpu)
+    y, part = ops.conv_dgrad_stats(desc, x, wt)
+    assert torch.equal(y, ops.conv_dgrad(desc, x, wt))
+    if part is not None:                                           # (fusing is allowed whenever the tile counts happen to match)
+        assert part[1] >= 1
+    C = y.shape[1]
+    outs = [ops.bn_train_fwd(y, None, torch.ones(C, device=gpu), torch.zeros(C, device=gpu), torch.zeros(C, device=gpu),
+                             torch.ones(C, device=gpu), torch.zeros((), dtype=torch.int64, device=gpu), 1e-5, 0.1, True, partial=pp)[0]
+            for pp in (None, part)]
+    assert float((outs[0] - outs[1]).abs().max()) <= 1e-5
