@@ -907,6 +907,164 @@ __global__ __launch_bounds__(256, 3) void wgrad_kw_kernel(const WgradKwArgs p) {
       }
 }
 
+// ------------------------------------------------------------------------------------ wgrad, 3x3 / 4x4 stride 2 pad 1 (bf16)
+// Same idea for stride 2 (the strided convs of the backbone / adversarial heads and the conv-form of the 4x4 transposed
+// convs): tap kw of output pixel ox reads input column 2*ox + kw - 1, so the taps fall on TWO column-parity images of the
+// input row -- E[j] = x[2j], O[j] = x[2j+1] -- as shifted reads: kw0 = O[ox-1], kw1 = E[ox], kw2 = O[ox], kw3 = E[ox+1].
+// Per 64-pixel step a block stages one DY tile and the two parity tiles (as much X data as ONE tap of the generic kernel)
+// and multiplies 3 (4) taps out of them.
+struct WgradKw2Args {
+  const void* X; const void* DY; float* out;
+  int H, W, Ho, Ci, Co;
+  int lw, lwo;                  // log2(min(Wo,64)), log2(Wo)
+  int M, rows_per_split, ldw;
+  long slab_stride;
+  int nto, nci;
+  unsigned x_bytes, dy_bytes;
+  FastDiv dHo;
+};
+
+template <int MT, int KW>
+__global__ __launch_bounds__(256, KW == 4 ? 2 : 3) void wgrad_kw2_kernel(const WgradKw2Args p) {
+  constexpr int BO = 64 * MT, BKM = 64;
+  constexpr int CPRY = BO / 8, RPY = 256 / CPRY, NPY = BKM / RPY;
+  constexpr int XROWS = 64 + 4 * 8 + 4;
+  __shared__ __attribute__((aligned(16))) char smem[BKM * 256 + 2 * XROWS * 128 + 2 * BKM * 8];
+  char* ys = smem;
+  char* xe = smem + BKM * 256;                 // even input columns
+  char* xo = xe + XROWS * 128;                 // odd input columns
+  int2* rowinfo = reinterpret_cast<int2*>(smem + BKM * 256 + 2 * XROWS * 128);   // [2][BKM]: {input pixel of (2oy, 2ox), oy}
+
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int ntile = p.nto * KW * p.nci;
+  const int lid = xcd_remap(blockIdx.x, gridDim.x);
+  const int split = lid / ntile;
+  int tile = lid - split * ntile;
+  const int ot = tile / (KW * p.nci); tile -= ot * KW * p.nci;
+  const int kh = tile / p.nci, cit = tile - kh * p.nci;
+  const int o0 = ot * BO, ci0 = cit * 64, tdy = kh - 1;
+  const int wm0 = (wave >> 1) * (32 * MT), wn0 = (wave & 1) * 32;
+
+  const __amdgpu_buffer_rsrc_t rsX = make_rsrc(p.X, p.x_bytes), rsY = make_rsrc(p.DY, p.dy_bytes);
+  const int lcy = t % CPRY, lry = t / CPRY;
+  const int lcx = t & 7, lrx = t >> 3;
+  const bool ook = (o0 + lcy * 8) < p.Co;
+  const bool cok = (ci0 + lcx * 8) < p.Ci;
+  const int mbeg = split * p.rows_per_split;
+  const int mend = min(p.M, mbeg + p.rows_per_split);
+
+  for (int i = t; i < 2 * XROWS * 8; i += 256) reinterpret_cast<uint4*>(xe)[i] = make_uint4(0, 0, 0, 0);
+
+  uint4 ry[NPY], re[2], ro[2];
+  auto decode_rows = [&](int mt0, int buf) {
+    if (t < BKM) {
+      const unsigned m = (unsigned)(mt0 + t);
+      const unsigned q = m >> p.lwo, ox = m & ((1u << p.lwo) - 1);
+      const unsigned n = fd_div(q, p.dHo);
+      const int oy = (int)(q - n * p.Ho);
+      rowinfo[buf * BKM + t] = (m < (unsigned)p.M) ? make_int2(((int)n * p.H + 2 * oy) * p.W + 2 * (int)ox, oy) : make_int2(0, -(1 << 20));
+    }
+  };
+  auto load_tile = [&](int mt0, int buf) {
+#pragma unroll
+    for (int i = 0; i < NPY; ++i) {
+      const int m = mt0 + lry + RPY * i;
+      ry[i] = buf_load16(rsY, (m < mend && ook) ? (m * p.Co + o0 + lcy * 8) * 2 : OOB_OFF);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int2 ri = rowinfo[buf * BKM + lrx + 32 * i];
+      const bool ok = cok && (unsigned)(2 * ri.y + tdy) < (unsigned)p.H;
+      const int off = ((ri.x + tdy * p.W) * p.Ci + ci0 + lcx * 8) * 2;
+      re[i] = buf_load16(rsX, ok ? off : OOB_OFF);
+      ro[i] = buf_load16(rsX, ok ? off + p.Ci * 2 : OOB_OFF);
+    }
+  };
+  auto store_tile = [&]() {
+#pragma unroll
+    for (int i = 0; i < NPY; ++i) *reinterpret_cast<uint4*>(ys + swz256(lry + RPY * i, lcy)) = ry[i];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int r = lrx + 32 * i;
+      const int a = swzx(r + 2 + 4 * (r >> p.lw), lcx);
+      *reinterpret_cast<uint4*>(xe + a) = re[i];
+      *reinterpret_cast<uint4*>(xo + a) = ro[i];
+    }
+  };
+
+  f32x16_t acc[KW][MT];
+#pragma unroll
+  for (int a = 0; a < KW; ++a)
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][i][r] = 0.f;
+
+  const int r31 = lane & 31, hi = lane >> 5;
+  const int tg = lane >> 4, tq = (lane & 15) >> 2, tp = lane & 3;
+  int trA[MT][2], trB[KW][2];
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int row = 8 * (tg >> 1) + tq + 4 * u;
+#pragma unroll
+    for (int i = 0; i < MT; ++i) trA[i][u] = swz256(row, (wm0 + i * 32) / 8 + 2 * (tg & 1) + (tp >> 1)) + 8 * (tp & 1);
+    const int R0 = row + 2 + 4 * (row >> p.lw);
+    const int ch = wn0 / 8 + 2 * (tg & 1) + (tp >> 1);
+#pragma unroll
+    for (int k = 0; k < KW; ++k) {
+      // kw0 = O[ox-1], kw1 = E[ox], kw2 = O[ox], kw3 = E[ox+1]   (offsets relative to the even image)
+      const int shift = k == 0 ? -1 : (k == 3 ? 1 : 0);
+      trB[k][u] = swzx(R0 + shift, ch) + 8 * (tp & 1) + ((k & 1) ? 0 : XROWS * 128);
+    }
+  }
+  decode_rows(mbeg, 0);
+  __syncthreads();
+  if (mbeg < mend) load_tile(mbeg, 0);
+  int buf = 0;
+  for (int mt0 = mbeg; mt0 < mend; mt0 += BKM, buf ^= 1) {
+    __syncthreads();
+    store_tile();
+    decode_rows(mt0 + BKM, buf ^ 1);
+    __syncthreads();
+    if (mt0 + BKM < mend) load_tile(mt0 + BKM, buf ^ 1);
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      typedef __attribute__((address_space(3))) bf16x4_t* lds4;
+      const int eoff = (16 * s + 4 * ((16 * s) >> p.lw)) * 128;
+      bf16x8_t a[MT], b[KW];
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+        bf16x4_t a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4)(ys + trA[i][0] + s * 4096));
+        bf16x4_t a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4)(ys + trA[i][1] + s * 4096));
+        a[i] = __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7);
+      }
+#pragma unroll
+      for (int k = 0; k < KW; ++k) {
+        bf16x4_t b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4)(xe + trB[k][0] + eoff));
+        bf16x4_t b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4)(xe + trB[k][1] + eoff));
+        b[k] = __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7);
+      }
+#pragma unroll
+      for (int k = 0; k < KW; ++k)
+#pragma unroll
+        for (int i = 0; i < MT; ++i) acc[k][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[k], acc[k][i], 0, 0, 0);
+    }
+    __builtin_amdgcn_s_setprio(0);
+  }
+  float* out = p.out + (size_t)split * p.slab_stride;
+#pragma unroll
+  for (int k = 0; k < KW; ++k)
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int o = o0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+        const int c = ci0 + wn0 + r31;
+        if (o < p.Co && c < p.Ci) out[(size_t)o * p.ldw + (kh * KW + k) * p.Ci + c] = acc[k][i][r];
+      }
+}
+
 // Fixed-order slab reduction.  SL "slab lanes" share each float4 column: lane j sums slabs j, j+SL, ... (4 loads in
 // flight), the SL partial sums are then added in lane order -- the order depends only on (S, SL), never on timing.
 template <int SL>
@@ -1251,7 +1409,7 @@ static int conv_dgrad_impl(const mi355_conv_desc* d, const void* dy, const void*
   return MI355_OK;
 }
 
-struct WgradPlan { int S, rows_per_split, nto, nti, ldw, kw3, mt; };
+struct WgradPlan { int S, rows_per_split, nto, nti, ldw, kw3, mt, kw2; };
 static int ilog2_exact(int v);
 static const int g_wgrad_blocks = getenv("MI355_WG_BLOCKS") ? atoi(getenv("MI355_WG_BLOCKS")) : 768;
 static WgradPlan plan_wgrad(const mi355_conv_desc* d) {
@@ -1263,8 +1421,14 @@ static WgradPlan plan_wgrad(const mi355_conv_desc* d) {
   w.kw3 = kw3_on && d->dtype == MI355_BF16 && d->kh == 3 && d->kw == 3 && d->stride == 1 && d->pad == 1 &&
           d->Wi >= 8 && ilog2_exact(d->Wi) >= 0;
   w.mt = d->Co <= 64 ? 1 : 2;
+  // 3x3 / 4x4, stride 2, pad 1 in bf16, output width a power of two in [8, 64]: the parity-image kernel (wgrad_kw2_kernel)
+  static const int kw2_on = getenv("MI355_WGRAD_KW2") ? atoi(getenv("MI355_WGRAD_KW2")) : 1;
+  w.kw2 = kw2_on && d->dtype == MI355_BF16 && d->kh == d->kw && (d->kh == 3 || d->kh == 4) && d->stride == 2 && d->pad == 1 &&
+          d->Hi % 2 == 0 && d->Wi % 2 == 0 && d->Ho == d->Hi / 2 && d->Wo == d->Wi / 2 && d->Wo >= 8 && d->Wo <= 64 &&
+          ilog2_exact(d->Wo) >= 0;
   long tiles;
-  if (w.kw3) { w.nto = cdiv(d->Co, 64 * w.mt); w.nti = cdiv(d->Ci, 64); tiles = (long)w.nto * 3 * w.nti; }
+  if (w.kw2) { w.nto = cdiv(d->Co, 64 * w.mt); w.nti = cdiv(d->Ci, 64); tiles = (long)w.nto * d->kh * w.nti; }
+  else if (w.kw3) { w.nto = cdiv(d->Co, 64 * w.mt); w.nti = cdiv(d->Ci, 64); tiles = (long)w.nto * 3 * w.nti; }
   else { w.nto = cdiv(d->Co, 128); w.nti = cdiv(w.ldw, 128); tiles = (long)w.nto * w.nti; }
   // split count: fill the chip (3 blocks per CU), but keep >= 16 reduction steps per block while at least one block
   // per CU remains -- short blocks are all prologue / epilogue and every split costs a full fp32 slab write + read.
@@ -1300,6 +1464,25 @@ extern "C" int mi355_conv_wgrad(const mi355_conv_desc* d, const void* x, const v
   const size_t need = (size_t)w.S * d->Co * w.ldw * sizeof(float);
   const bool direct = (w.S == 1 && !accumulate);
   if (!direct && (ws == nullptr || ws_bytes < need)) MI_FAIL(MI355_EWORKSPACE, "wgrad workspace %zu < %zu", ws_bytes, need);
+  if (w.kw2) {
+    WgradKw2Args k; memset(&k, 0, sizeof(k));
+    k.X = x; k.DY = dy; k.out = direct ? dw : reinterpret_cast<float*>(ws);
+    k.H = d->Hi; k.W = d->Wi; k.Ho = d->Ho; k.Ci = d->Ci; k.Co = d->Co;
+    k.lwo = ilog2_exact(d->Wo); k.lw = k.lwo > 6 ? 6 : k.lwo;
+    k.M = d->N * d->Ho * d->Wo; k.rows_per_split = w.rows_per_split; k.ldw = w.ldw;
+    k.slab_stride = (long)d->Co * w.ldw; k.nto = w.nto; k.nci = w.nti;
+    k.x_bytes = (unsigned)((long)d->N * d->Hi * d->Wi * d->Ci * 2); k.dy_bytes = (unsigned)((long)k.M * d->Co * 2);
+    k.dHo = make_fastdiv(d->Ho);
+    {
+      ProfScope ps(st, 2.0 * k.M * (double)d->Co * w.ldw, (double)k.x_bytes + (double)k.dy_bytes + 4.0 * d->Co * w.ldw);
+      dim3 grid(w.nto * d->kh * w.nti * w.S);
+      if (d->kh == 3) { if (w.mt == 1) hipLaunchKernelGGL((wgrad_kw2_kernel<1, 3>), grid, dim3(256), 0, st, k); else hipLaunchKernelGGL((wgrad_kw2_kernel<2, 3>), grid, dim3(256), 0, st, k); }
+      else { if (w.mt == 1) hipLaunchKernelGGL((wgrad_kw2_kernel<1, 4>), grid, dim3(256), 0, st, k); else hipLaunchKernelGGL((wgrad_kw2_kernel<2, 4>), grid, dim3(256), 0, st, k); }
+      MI_CHECK_LAUNCH("wgrad_kw2");
+    }
+    if (!direct) launch_slab_reduce(reinterpret_cast<const float*>(ws), dw, k.slab_stride, w.S, k.slab_stride, accumulate, st);
+    return MI355_OK;
+  }
   if (w.kw3) {
     WgradKwArgs k; memset(&k, 0, sizeof(k));
     k.X = x; k.DY = dy; k.out = direct ? dw : reinterpret_cast<float*>(ws);

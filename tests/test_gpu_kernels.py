@@ -55,6 +55,11 @@ CONV_CASES = [
     (1, 128, 32, 32, 256, 3, 1, 1),   # W = 32, two output-channel tiles x two input-channel tiles
     (1, 64, 20, 64, 128, 3, 1, 1),    # W = 64: one image row per tile, H not a power of two
     (1, 64, 6, 128, 64, 3, 1, 1),     # W = 128: half rows with halo pixels fetched from the neighbours
+    # 3x3 / 4x4 stride 2: the parity-image wgrad kernel (bf16), one case per output width
+    (1, 64, 24, 32, 128, 3, 2, 1),    # Wo = 16, Ho = 12 (not a power of two)
+    (1, 64, 64, 64, 64, 4, 2, 1),     # 4x4 (conv-form of a transposed conv), Wo = 32, 64 output channels
+    (1, 64, 128, 128, 128, 3, 2, 1),  # Wo = 64: one image row per tile
+    (2, 128, 32, 32, 256, 4, 2, 1),   # 4x4, two output-channel tiles x two input-channel tiles
     (32, 64, 64, 64, 256, 3, 1, 1),   # 2048 output tiles: the shared-A-tile (KW3) forward / dgrad kernel is chosen by default
     (64, 64, 64, 64, 256, 3, 1, 1),   # 4096 output tiles: its 256x128 macro-tile build
 ]
