@@ -250,6 +250,17 @@ def main():
                 'avg_launch_us': round(ms * 1e3 / launches, 2),
                 'event_dispatch_overhead_us': round(ops.prof_event_overhead_us(256), 2),
                 'conv_ms_per_step': round(ms / n_prof, 3)}
+        # the family mixes regimes: launches whose algorithmic intensity is below the machine balance (2.5 PFLOP/s / 8 TB/s =
+        # 312 FLOP/B: the 1x1 convs, the stem) are HBM-bound and priced against 8 TB/s, the others against MFMA
+        sp = ops.prof_read_split(PEAK_TFLOPS[args.dtype] * 1e12 / 8e12)
+        if sp[0] > 0 and sp[4] > 0:
+            roof['split'] = {
+                'hbm_bound': {'launches_per_step': int(sp[3]) // n_prof, 'ms_per_step': round(sp[0] / n_prof, 3),
+                              'achieved_GBps_algorithmic': round(sp[2] / (sp[0] * 1e-3) / 1e9, 1), 'peak_GBps': 8000.0,
+                              'frac': round(sp[2] / (sp[0] * 1e-3) / 8e12, 4)},
+                'mfma_bound': {'launches_per_step': int(sp[7]) // n_prof, 'ms_per_step': round(sp[4] / n_prof, 3),
+                               'achieved_TFLOPs': round(sp[5] / (sp[4] * 1e-3) / 1e12, 1), 'peak_TFLOPs': peak,
+                               'frac': round(sp[5] / (sp[4] * 1e-3) / 1e12 / peak, 4)}}
     if world > 1:
         dist.barrier()
 

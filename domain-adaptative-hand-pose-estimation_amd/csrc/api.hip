@@ -16,6 +16,7 @@ namespace {
 struct ProfState {
   std::mutex mu; bool on = false;
   std::vector<hipEvent_t> ev;   // pairs
+  std::vector<double> lflops, lbytes;   // per launch (slot / 2)
   size_t used = 0; double flops = 0, bytes = 0; long launches = 0;
 };
 ProfState& P() { static ProfState s; return s; }
@@ -28,6 +29,8 @@ ProfScope::ProfScope(hipStream_t st, double flops, double bytes) : s(st), on(fal
     for (int i = 0; i < 2; ++i) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) return; p.ev.push_back(e); }
   }
   slot = (int)p.used; p.used += 2; p.flops += flops; p.bytes += bytes; p.launches += 1; on = true;
+  if (p.lflops.size() < p.used / 2) { p.lflops.resize(p.used / 2); p.lbytes.resize(p.used / 2); }
+  p.lflops[slot / 2] = flops; p.lbytes[slot / 2] = bytes;
   (void)hipEventRecord(p.ev[slot], s);
 }
 ProfScope::~ProfScope() {
@@ -84,5 +87,22 @@ extern "C" int mi355_prof_event_overhead_us(int n, void* stream, double* us) {
   for (int i = 0; i < n; ++i) { float t = 0; (void)hipEventElapsedTime(&t, ev[2 * i], ev[2 * i + 1]); tot += t; }
   for (auto& e : ev) (void)hipEventDestroy(e);
   *us = tot * 1e3 / n;
+  return MI355_OK;
+}
+
+// The event-timed launches split by arithmetic intensity (algorithmic FLOP per algorithmic byte): launches below
+// `flop_per_byte` are priced against HBM, the others against MFMA.  out[0..3] = {ms, flops, bytes, launches} of the
+// low-intensity class, out[4..7] of the high-intensity class.
+extern "C" int mi355_prof_read_split(double flop_per_byte, double* out) {
+  if (!out) MI_FAIL(MI355_EINVAL, "prof_read_split: out missing");
+  ProfState& p = P(); std::lock_guard<std::mutex> lk(p.mu);
+  for (int i = 0; i < 8; ++i) out[i] = 0.0;
+  for (size_t i = 0; i + 1 < p.used; i += 2) {
+    if (hipEventSynchronize(p.ev[i + 1]) != hipSuccess) MI_FAIL(MI355_ELAUNCH, "prof: event sync failed");
+    float t = 0; if (hipEventElapsedTime(&t, p.ev[i], p.ev[i + 1]) != hipSuccess) MI_FAIL(MI355_ELAUNCH, "prof: elapsed failed");
+    const double f = p.lflops[i / 2], b = p.lbytes[i / 2];
+    const int c = (b > 0 && f / b < flop_per_byte) ? 0 : 4;
+    out[c] += t; out[c + 1] += f; out[c + 2] += b; out[c + 3] += 1.0;
+  }
   return MI355_OK;
 }

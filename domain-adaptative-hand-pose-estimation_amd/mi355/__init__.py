@@ -79,6 +79,7 @@ SIGNATURES = {
     'mi355_cast_f32': (_I, [_P, _P, _L, _I, _P]),
     'mi355_prof_enable': (_I, [_I]),
     'mi355_spin_us': (_I, [_L, _P]),
+    'mi355_prof_read_split': (_I, [ctypes.c_double, ctypes.POINTER(ctypes.c_double)]),
     'mi355_prof_event_overhead_us': (_I, [_I, _P, ctypes.POINTER(ctypes.c_double)]),
     'mi355_prof_reset': (_I, []),
     'mi355_prof_read': (_I, [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_long),

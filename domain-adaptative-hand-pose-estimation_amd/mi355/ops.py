@@ -390,6 +390,12 @@ def prof_event_overhead_us(n=256):
     return us.value
 
 
+def prof_read_split(flop_per_byte):
+    out = (ctypes.c_double * 8)()
+    call('mi355_prof_read_split', float(flop_per_byte), out)
+    return list(out)
+
+
 def prof_enable(on):
     call('mi355_prof_enable', int(on))
 

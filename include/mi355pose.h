@@ -238,6 +238,8 @@ int mi355_cast_f32(const float* in, void* out, long n, int dtype, void* stream);
 int mi355_prof_enable(int on);
 /* idle spin of `us` microseconds on the stream (measurement aid: queue launches behind it so the GPU never waits for the host) */
 int mi355_spin_us(long us, void* stream);
+/* the timed launches split at an arithmetic intensity (FLOP / byte): out[0..3] = {ms, flops, bytes, launches} below it, out[4..7] above */
+int mi355_prof_read_split(double flop_per_byte, double* out);
 /* mean reading of an event pair around an empty kernel (the dispatch latency contained in every event-timed launch) */
 int mi355_prof_event_overhead_us(int n, void* stream, double* us);
 int mi355_prof_reset(void);
