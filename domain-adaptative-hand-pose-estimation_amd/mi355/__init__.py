@@ -199,6 +199,14 @@ _side = {}
 _pending = []
 # measured on MI355X (ResNet-50, B=64): 51.3 ms/iteration without, 52.1 ms with -> off by default
 SIDE_WGRAD = _os.environ.get('MI355_WGRAD_STREAM', '0') != '0'
+# MI355_WGRAD_STREAM=N with N > 1: only weight gradients of layers with at most N output rows go to the side stream
+SIDE_WGRAD_MAX_ROWS = int(_os.environ.get('MI355_WGRAD_STREAM', '0')) if int(_os.environ.get('MI355_WGRAD_STREAM', '0')) > 1 else None
+
+
+def side_wgrad_for(desc):
+    if not SIDE_WGRAD:
+        return False
+    return SIDE_WGRAD_MAX_ROWS is None or desc.N * desc.Ho * desc.Wo <= SIDE_WGRAD_MAX_ROWS
 
 
 def side_stream(device):

@@ -251,7 +251,7 @@ class _DeconvFn(torch.autograd.Function):
         dx = None
         if ctx.needs_input_grad[1]:
             g, acc = grad_slot(weight)
-            if _rt.SIDE_WGRAD:
+            if _rt.side_wgrad_for(desc):
                 with _rt.on_side(x.device, keep=(x, dy)):
                     ops.conv_wgrad(desc, dy, x, g, acc, ws_tag='side')      # conv-form input = dy, conv-form output = x
             else:
@@ -493,7 +493,7 @@ class Conv2d(nn.Module):
     def _wgrad(self, desc, x, dy, weight):
         g, acc = grad_slot(weight)
         if desc.Ci == self.in_channels:
-            if _rt.SIDE_WGRAD:
+            if _rt.side_wgrad_for(desc):
                 with _rt.on_side(x.device, keep=(x, dy)):
                     ops.conv_wgrad(desc, x, dy, g, acc, ws_tag='side')
             else:
