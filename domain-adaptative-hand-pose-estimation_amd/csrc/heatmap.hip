@@ -144,6 +144,7 @@ __global__ __launch_bounds__(256) void pseudo_label_kernel(const float* __restri
   if (gf && normalise) {
     mx = block_max<4>(mx, red);
     __syncthreads();
+    if (normalise == 2 && !(mx > 0.f)) return;          // guarded mode: an all-zero map stays zero (block-uniform)
     for (int i = threadIdx.x; i < S * S; i += 256) gf[base + i] = gf[base + i] / mx;   // 0/0 -> NaN as the reference
   }
 }

@@ -160,6 +160,7 @@ class PseudoLabelGenerator03(_GaussianLabels):
 class _Disparity(nn.Module):
     kind = 1          # ground-false rule of the builder kernel
     normalise = True  # per-map division by its maximum
+    guard_empty_maps = False   # extension (off = reference): leave an all-zero ground-false map at zero instead of 0/0 = NaN
 
     def __init__(self, pseudo_label_generator, criterion: nn.Module):
         super().__init__()
@@ -171,7 +172,8 @@ class _Disparity(nn.Module):
         gen = self.pseudo_label_generator
         # only the label the mode needs is materialised (the reference builds both and drops one)
         gt, gf = gen.labels(y.detach(), self.kind, extra=None if y_adv2 is None else y_adv2.detach(),
-                            normalise=self.normalise, want_gt=(mode == 'min'), want_gf=(mode == 'max'))
+                            normalise=(2 if (self.normalise and self.guard_empty_maps) else self.normalise),
+                            want_gt=(mode == 'min'), want_gf=(mode == 'max'))
         self.ground_truth, self.ground_false = gt, gf
         return self.criterion(y_adv, gt if mode == 'min' else gf, weight)
 

@@ -210,7 +210,9 @@ int mi355_scale_by_dev(const float* in, const float* g_dev, float* out, long n, 
  *       1 x1/x5 : gf = clip(1 - 10 gt, 0, 1)                                         (regda_7.py:3255-3256)
  *       2 x6    : gf = clip(clip(sum_k gt_k,0,1) - 10 gt, 0, 1)                      (regda_7.py:3614-3616)
  * extra (nullable, [B*K][S*S]): gf = clip(gf + extra - 100 gt, 0, 1)                 (:3542-3544, :3618-3620)
- * normalise!=0 : gf /= max(gf) per map (0/0 -> NaN as in the reference)              (:3546-3548, :3623-3625)
+ * normalise==1 : gf /= max(gf) per map (0/0 -> NaN as in the reference)              (:3546-3548, :3623-3625)
+ * normalise==2 : the same, but a map whose maximum is 0 is left at zero (synthetic-noise benchmarks: collapsed target
+ *                predictions make such maps after a few dozen iterations; not the reference's behaviour)
  * gt / gf outputs nullable.
  */
 int mi355_pseudo_label(const float* xy, const float* patch, int radius, int div, int S, int kind,

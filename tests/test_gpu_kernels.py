@@ -531,3 +531,31 @@ def test_fused_statistics_fall_back_when_phases_are_uneven(gpu):
                              torch.ones(C, device=gpu), torch.zeros((), dtype=torch.int64, device=gpu), 1e-5, 0.1, True, partial=pp)[0]
             for pp in (None, part)]
     assert float((outs[0] - outs[1]).abs().max()) <= 1e-5
+
+
+def test_guarded_max_normalisation_keeps_empty_maps_at_zero(gpu):
+    """normalise=2 (benchmark extension): a ground-false map whose maximum is 0 stays 0; normalise=1 keeps the reference's
+    0/0 = NaN; maps with a positive maximum are identical in both modes."""
+    from uda.model.regda_7 import RegressionDisparityx6, PseudoLabelGenerator
+    from uda.model.loss import JointsKLLoss
+    B, K, S = 2, 21, 64
+    y = torch.full((B, K, S, S), -1.0, device=gpu)
+    for k in range(K):                       # image 0: every key-point peaks at the same pixel; image 1: spread out
+        y[0, k, 30, 30] = 5.0
+        y[1, k, 5 + 2 * k, 7 + 2 * k] = 5.0
+    extra = torch.zeros(B, K, S, S, device=gpu)
+    extra[0] = -3.0                                            # a very negative y_adv2 term empties the maps of image 0
+    y_adv = torch.randn(B, K, S, S, device=gpu)
+    w = torch.ones(B, K, 1, device=gpu)
+    outs = {}
+    for guard in (False, True):
+        rd = RegressionDisparityx6(PseudoLabelGenerator(K, S, S), JointsKLLoss(epsilon=1e-7))
+        rd.guard_empty_maps = guard
+        loss = rd(y, y_adv, extra, w, mode='max')
+        outs[guard] = (rd.ground_false.clone(), float(loss))
+    gf_ref, l_ref = outs[False]
+    gf_g, l_g = outs[True]
+    assert torch.isnan(gf_ref[0]).any() and l_ref != l_ref                 # the reference rule: NaN
+    assert torch.isfinite(gf_g).all() and l_g == l_g
+    assert float(gf_g[0].abs().max()) == 0.0
+    assert torch.equal(gf_ref[1], gf_g[1])                                  # non-empty maps: same result
