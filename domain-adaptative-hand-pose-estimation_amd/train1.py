@@ -100,6 +100,12 @@ def main(args):
     step, opts, scheds = build_training(model, heatmap_size=args.heatmap_size, lr=args.lr, momentum=args.momentum, wd=args.wd,
                                         lr_gamma=args.lr_gamma, lr_decay=args.lr_decay, trade_off=args.trade_off,
                                         num_keypoints=num_keypoints)
+    if args.synthetic:
+        # noise images make the target predictions collapse within a few dozen iterations; the reference's per-map
+        # max-normalisation then divides 0 by 0 (regda_7.py:3623-3625).  Synthetic runs keep such maps at zero instead.
+        for c in step.crit.values():
+            if hasattr(c, 'guard_empty_maps'):
+                c.guard_empty_maps = True
     start_epoch = 0
     if args.resume is None:
         if args.pretrain is None or (args.synthetic and not os.path.exists(args.pretrain)):
