@@ -309,3 +309,36 @@ def test_optin_bn_backward_fusion_matches_default(gpu):
             continue
         e = float((b[k] - t).norm()) / float(t.norm())
         assert e <= 1e-4, '%s: %.3e' % (k, e)
+
+
+def test_bf16_training_reduces_the_supervised_loss(gpu):
+    """End-to-end sanity of the throughput mode: 80 A/B/C iterations on one fixed synthetic batch (ResNet-18, 128x128, B=4,
+    bf16, guarded normalisation as in bench.py) stay finite and bring the supervised KL loss down by more than a third."""
+    import mi355
+    import uda.model as models
+    from mi355.da_step import build_training
+    from uda.model.pose_resnet2 import Upsampling
+    from uda.model.regda_7 import PoseResNetx9
+    from utils.synthetic import make_batch
+    mi355.set_compute_dtype('bf16')
+    try:
+        torch.manual_seed(1)
+        bb = models.resnet18(pretrained=False)
+        model = PoseResNetx9(bb, Upsampling(bb.out_features), 256, 21, num_head_layers=2, finetune=True).to(gpu)
+        step, opts, scheds = build_training(model, heatmap_size=32)
+        for c in step.crit.values():
+            if hasattr(c, 'guard_empty_maps'):
+                c.guard_empty_maps = True
+        batch = make_batch(4, 128, 32, seed=3, device=gpu)
+        first = last = None
+        for it in range(80):
+            out = step.run(batch)
+            for s in scheds.values():
+                s.step()
+            if it == 0:
+                first = float(out['loss_s'])
+        last = [float(out[k]) for k in ('loss_s', 'loss_gf', 'loss_gt')]
+        assert all(v == v for v in last), last
+        assert last[0] < 0.66 * first, (first, last)
+    finally:
+        mi355.set_compute_dtype('f32')
