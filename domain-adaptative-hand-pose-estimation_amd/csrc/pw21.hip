@@ -55,7 +55,7 @@ __global__ __launch_bounds__(256) void pw_c2k_kernel(const T* __restrict__ x, co
 template <typename T>
 __global__ __launch_bounds__(256) void pw_k2c_kernel(const float* __restrict__ y, const float* __restrict__ w, const float* __restrict__ bias,
                                                       const T* __restrict__ res, const float* __restrict__ scale_dev, T* __restrict__ out,
-                                                      int HW, int C, int K, int wtr) {
+                                                      int HW, int C, int K, int wtr, float* __restrict__ stat_partial) {
   constexpr int CH = Chunk<T>::N;
   constexpr int CG = 256 / 8;                               // 32 channel-chunks per block pass, 8 pixel groups
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -74,7 +74,7 @@ __global__ __launch_bounds__(256) void pw_k2c_kernel(const float* __restrict__ y
   __syncthreads();
   const int cg = t & (CG - 1), pg = t >> 5;                 // pg: 8 pixels each
   const int c0 = cbase + cg * CH;
-  if (c0 >= C) return;
+  if (c0 >= C && !stat_partial) return;
   float acc[8][CH];
 #pragma unroll
   for (int i = 0; i < 8; ++i)
@@ -92,13 +92,17 @@ __global__ __launch_bounds__(256) void pw_k2c_kernel(const float* __restrict__ y
     }
   }
   const float scale = scale_dev ? *scale_dev : 1.f;
+  const bool cok = c0 < C;
   float b[CH];
 #pragma unroll
-  for (int e = 0; e < CH; ++e) b[e] = bias ? bias[c0 + e] : 0.f;
+  for (int e = 0; e < CH; ++e) b[e] = (bias && cok) ? bias[c0 + e] : 0.f;
+  float sn = 0.f, smean[CH], sm2[CH];       // BatchNorm statistics of the stored (rounded) values, as in the gather epilogue
+#pragma unroll
+  for (int e = 0; e < CH; ++e) { smean[e] = 0.f; sm2[e] = 0.f; }
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     const int p = p0 + pg * 8 + i;
-    if (p >= HW) continue;
+    if (p >= HW || !cok) continue;
     const size_t off = ((size_t)n * HW + p) * C + c0;
     float v[CH];
 #pragma unroll
@@ -109,6 +113,44 @@ __global__ __launch_bounds__(256) void pw_k2c_kernel(const float* __restrict__ y
 #pragma unroll
     for (int e = 0; e < CH; ++e) v[e] *= scale;
     Chunk<T>::store(out + off, v);
+    if (stat_partial) {
+      sn += 1.f; const float inv = 1.f / sn;
+#pragma unroll
+      for (int e = 0; e < CH; ++e) { const float q = (float)(T)v[e]; const float d = q - smean[e]; smean[e] += d * inv; sm2[e] += d * (q - smean[e]); }
+    }
+  }
+  if (!stat_partial) return;
+  // fold the 8 pixel groups: lanes 32..63 onto 0..31 inside a wave, then the four waves in order through LDS (fixed order)
+  {
+    const float nb = __shfl_down(sn, 32, 64);
+    const float nt = sn + nb, f = nt > 0.f ? nb / nt : 0.f;
+#pragma unroll
+    for (int e = 0; e < CH; ++e) {
+      const float mb = __shfl_down(smean[e], 32, 64), vb = __shfl_down(sm2[e], 32, 64);
+      const float d = mb - smean[e];
+      smean[e] += d * f; sm2[e] += vb + d * d * sn * f;
+    }
+    sn = nt;
+  }
+  __syncthreads();                                            // ys / ws are dead: reuse the front of the LDS
+  float* sp = reinterpret_cast<float*>(smem);                 // [4 waves][CG*CH][3]
+  const int lane = t & 63, wave = t >> 6;
+  if (lane < 32) {
+#pragma unroll
+    for (int e = 0; e < CH; ++e) { float* q = sp + ((size_t)wave * CG * CH + cg * CH + e) * 3; q[0] = sn; q[1] = smean[e]; q[2] = sm2[e]; }
+  }
+  __syncthreads();
+  if (t < CG * CH && cbase + t < C) {
+    float nn = 0.f, mean = 0.f, m2 = 0.f;
+#pragma unroll
+    for (int w2 = 0; w2 < 4; ++w2) {
+      const float* q = sp + ((size_t)w2 * CG * CH + t) * 3;
+      const float nb = q[0];
+      if (nb > 0.f) { const float nt = nn + nb, f = nb / nt, d = q[1] - mean; mean += d * f; m2 += q[2] + d * d * nn * f; nn = nt; }
+    }
+    const size_t slice = (size_t)n * gridDim.x + blockIdx.x;
+    float* o = stat_partial + (slice * C + cbase + t) * 3;
+    o[0] = nn; o[1] = mean; o[2] = m2;
   }
 }
 
@@ -209,15 +251,29 @@ extern "C" int mi355_pw_c2k(const void* x, const float* w, const float* bias, fl
   return MI355_OK;
 }
 
-extern "C" int mi355_pw_k2c(const float* y, const float* w, const float* bias, const void* residual, const float* scale_dev, void* out,
-                            int N, int HW, int C, int K, int w_transposed, int dtype, void* stream) {
+static int pw_k2c_impl(const float* y, const float* w, const float* bias, const void* residual, const float* scale_dev, void* out,
+                       int N, int HW, int C, int K, int w_transposed, int dtype, float* stat_partial, void* stream) {
   int CH; if (int e = pw_check(N, HW, C, K, dtype, &CH)) return e;
   const size_t smem = (size_t)K * PW_PIX * 4 + (size_t)K * 32 * CH * 4;
   dim3 grid(cdiv(HW, PW_PIX), N, cdiv(C, 32 * CH));
-  if (dtype == MI355_BF16) hipLaunchKernelGGL(pw_k2c_kernel<bf16_t>, grid, dim3(256), smem, as_stream(stream), y, w, bias, (const bf16_t*)residual, scale_dev, (bf16_t*)out, HW, C, K, w_transposed);
-  else hipLaunchKernelGGL(pw_k2c_kernel<float>, grid, dim3(256), smem, as_stream(stream), y, w, bias, (const float*)residual, scale_dev, (float*)out, HW, C, K, w_transposed);
+  if (dtype == MI355_BF16) hipLaunchKernelGGL(pw_k2c_kernel<bf16_t>, grid, dim3(256), smem, as_stream(stream), y, w, bias, (const bf16_t*)residual, scale_dev, (bf16_t*)out, HW, C, K, w_transposed, stat_partial);
+  else hipLaunchKernelGGL(pw_k2c_kernel<float>, grid, dim3(256), smem, as_stream(stream), y, w, bias, (const float*)residual, scale_dev, (float*)out, HW, C, K, w_transposed, stat_partial);
   MI_CHECK_LAUNCH("pw_k2c");
   return MI355_OK;
+}
+extern "C" int mi355_pw_k2c(const float* y, const float* w, const float* bias, const void* residual, const float* scale_dev, void* out,
+                            int N, int HW, int C, int K, int w_transposed, int dtype, void* stream) {
+  return pw_k2c_impl(y, w, bias, residual, scale_dev, out, N, HW, C, K, w_transposed, dtype, nullptr, stream);
+}
+// the same with the BatchNorm statistics of the output from the epilogue: partial[N * ceil(HW/64)][C][n, mean, M2]
+extern "C" int mi355_pw_k2c_stats(const float* y, const float* w, const float* bias, const void* residual, const float* scale_dev,
+                                  void* out, int N, int HW, int C, int K, int w_transposed, int dtype, float* partial,
+                                  size_t partial_bytes, int* nslices, void* stream) {
+  if (!partial || !nslices) MI_FAIL(MI355_EINVAL, "pw_k2c_stats: partial / nslices must be given");
+  const int ns = N * cdiv(HW, PW_PIX);
+  if ((size_t)ns * C * 3 * sizeof(float) > partial_bytes) MI_FAIL(MI355_EWORKSPACE, "pw_k2c_stats: partial buffer too small");
+  *nslices = ns;
+  return pw_k2c_impl(y, w, bias, residual, scale_dev, out, N, HW, C, K, w_transposed, dtype, partial, stream);
 }
 
 static int pw_slices(int N, int HW, int* pps) {

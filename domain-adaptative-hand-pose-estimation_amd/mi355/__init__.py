@@ -64,6 +64,7 @@ SIGNATURES = {
     'mi355_conv1x1_heatmap': (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     'mi355_pw_c2k': (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     'mi355_pw_k2c': (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    'mi355_pw_k2c_stats': (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _Z, _P, _P]),
     'mi355_pw_wgrad_workspace': (_Z, [_I, _I, _I, _I]),
     'mi355_pw_wgrad': (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _Z, _P]),
     'mi355_hm_rowsum': (_I, [_P, _P, _I, _I, _I, _I, _P, _Z, _P]),

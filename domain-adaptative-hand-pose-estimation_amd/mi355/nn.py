@@ -399,7 +399,10 @@ class _PwK2CFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, hm, weight, bias, residual, dtype, mod=None):
         C = weight.shape[0]
-        out = ops.pw_k2c(hm, weight.detach(), bias, C, dtype, residual=residual)
+        if mod is not None and mod._want_stats():
+            out, mod._last_partial = ops.pw_k2c_stats(hm, weight.detach(), bias, C, dtype, residual=residual)
+        else:
+            out = ops.pw_k2c(hm, weight.detach(), bias, C, dtype, residual=residual)
         ctx.has_bias = bias is not None
         ctx.mod = mod
         ctx.save_for_backward(hm, weight, bias)
@@ -519,7 +522,7 @@ class Conv2d(nn.Module):
                 x = x.float().contiguous()
             if not x.is_cuda:
                 raise Mi355Error('mi355 layers need CUDA/HIP tensors; there is no CPU fallback')
-            return _PwK2CFn.apply(x, self.weight, self.bias, residual, dtype, self)
+            return _take_partial(self, _PwK2CFn.apply(x, self.weight, self.bias, residual, dtype, self))
         if x.shape[1] == self.in_channels and self.in_channels != self._cin_pad(dtype):
             x = ops.to_nhwc(x if (x.dtype == torch.float32 and x.is_contiguous()) else x.float().contiguous(),
                             dtype, self._cin_pad(dtype))

@@ -267,6 +267,18 @@ def pw_k2c(y, w, bias, C, dtype, residual=None, scale_dev=None, w_transposed=Fal
     return out
 
 
+def pw_k2c_stats(y, w, bias, C, dtype, residual=None):
+    """pw_k2c + BatchNorm statistics partials of its output.  Returns (out, (partial, nslices))."""
+    N, K, H, W = y.shape
+    out = nhwc_empty(N, C, H, W, dtype, y.device)
+    ns_max = N * ((H * W + 63) // 64)
+    partial = torch.empty(ns_max * C * 3, dtype=torch.float32, device=y.device)
+    ns = ctypes.c_int(0)
+    call('mi355_pw_k2c_stats', ptr(y), ptr(w), ptr(bias), ptr(residual), None, ptr(out), N, H * W, C, K, 0,
+         dtype_code(dtype), ptr(partial), partial.numel() * 4, ctypes.byref(ns), stream_ptr())
+    return out, (partial, ns.value)
+
+
 def pw_wgrad(x, y, dw, kc_layout, accumulate):
     N, C, H, W = x.shape
     K = y.shape[1]

@@ -48,6 +48,7 @@ class make_head(nn.Module):
         self.heatmap_conv = Conv2d(21, 256, 1, 1, 0, bias=True)
         self.feature_conv = Conv2d(256, 256, 1, 1, 0, bias=True)
         self.model = _simple_head(num_layers, channel_dim, num_keypoints)
+        self.heatmap_conv.bn_follows = True      # its output goes straight into last_lay's BatchNorm: statistics in the epilogue
         self.last_lay = _fusion_tail(1, channel_dim)
 
     def forward(self, feature, heatmap):
@@ -65,6 +66,7 @@ class make_head2(nn.Module):
         self.feature_conv = Conv2d(256, 256, 3, 2, 1, bias=True)
         self.upsample = nn.Upsample(size=64, mode='bilinear')   # unused in the reference forward as well
         self.model = _simple_head(num_layers, channel_dim, num_keypoints)
+        self.heatmap_conv.bn_follows = True      # its output goes straight into last_lay's BatchNorm: statistics in the epilogue
         self.last_lay = _fusion_tail(2 - 1, channel_dim)        # reference loops range(num_layers - 1) with 2
 
     def forward(self, feature, heatmap):

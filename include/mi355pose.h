@@ -177,6 +177,11 @@ int mi355_pw_c2k(const void* x, const float* w, const float* bias, float* y, int
 int mi355_pw_k2c(const float* y, const float* w, const float* bias, const void* residual,
                  const float* scale_dev, void* out, int N, int HW, int C, int K, int w_transposed, int dtype,
                  void* stream);
+/* mi355_pw_k2c with the BatchNorm statistics of its output from the epilogue (the BN in front of `last_lay`, regda_7.py:4551-4561):
+ * partial[N * ceil(HW/64)][C][n, mean, M2], consumed by mi355_bn_train_fwd_partials */
+int mi355_pw_k2c_stats(const float* y, const float* w, const float* bias, const void* residual, const float* scale_dev,
+                       void* out, int N, int HW, int C, int K, int w_transposed, int dtype, float* partial,
+                       size_t partial_bytes, int* nslices, void* stream);
 size_t mi355_pw_wgrad_workspace(int N, int HW, int C, int K);
 int mi355_pw_wgrad(const void* x, const float* y, float* dw, int kc_layout, int accumulate, int N, int HW,
                    int C, int K, int dtype, void* ws, size_t ws_bytes, void* stream);

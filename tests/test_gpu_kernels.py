@@ -559,3 +559,28 @@ def test_guarded_max_normalisation_keeps_empty_maps_at_zero(gpu):
     assert torch.isfinite(gf_g).all() and l_g == l_g
     assert float(gf_g[0].abs().max()) == 0.0
     assert torch.equal(gf_ref[1], gf_g[1])                                  # non-empty maps: same result
+
+
+@pytest.mark.parametrize('dt', ['f32', 'bf16'])
+@pytest.mark.parametrize('shape', [(2, 21, 64, 256, 16, 16), (3, 21, 60, 256, 10, 10), (2, 21, 64, 128, 8, 8)])
+def test_pointwise_k2c_epilogue_bn_statistics(gpu, dt, shape):
+    """21 -> C point-wise conv (+bias, +residual) with the BatchNorm statistics of its output from the epilogue == stand-alone pass."""
+    ops = _ops()
+    N, K, _, C, H, W = shape
+    hm = randn(41, N, K, H, W).to(gpu)
+    w = (0.2 * randn(42, C, K)).to(gpu)
+    b = (0.1 * randn(43, C)).to(gpu)
+    res = _nhwc(_round(randn(44, N, C, H, W), dt), dt, gpu)
+    y0 = ops.pw_k2c(hm, w, b, C, DT[dt], residual=res)
+    y1, part = ops.pw_k2c_stats(hm, w, b, C, DT[dt], residual=res)
+    assert torch.equal(y0, y1) and part[1] == N * ((H * W + 63) // 64)
+    gamma, beta = (1 + 0.1 * randn(23, C)).to(gpu), (0.1 * randn(24, C)).to(gpu)
+    outs = []
+    for pp in (None, part):
+        rm, rv = torch.zeros(C, device=gpu), torch.ones(C, device=gpu)
+        nbt = torch.zeros((), dtype=torch.int64, device=gpu)
+        outs.append(ops.bn_train_fwd(y1, None, gamma, beta, rm, rv, nbt, 1e-5, 0.1, True, partial=pp) + (rm, rv))
+    (ya, ma, ia, rma, rva), (yb, mb, ib, rmb, rvb) = outs
+    assert torch.allclose(ma, mb, rtol=1e-5, atol=1e-6) and torch.allclose(ia, ib, rtol=2e-5, atol=1e-6)
+    assert torch.allclose(rma, rmb, rtol=1e-5, atol=1e-6) and torch.allclose(rva, rvb, rtol=2e-5, atol=1e-6)
+    assert float((ya.float() - yb.float()).abs().max()) <= (2e-2 if dt == 'bf16' else 1e-4)
