@@ -103,6 +103,20 @@ __global__ void scale_by_dev_kernel(const float* __restrict__ in, const float* _
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) out[i] = in[i] * k;
 }
 
+// out = in * (*g) on a feature tensor of n elements (n % 8 == 0 for bf16, % 4 for fp32): 16-byte accesses.
+template <typename T>
+__global__ __launch_bounds__(256) void scale_feature_kernel(const T* __restrict__ in, const float* __restrict__ g, T* __restrict__ out, long nvec) {
+  constexpr int PER = Chunk<T>::N;
+  const float k = *g;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (long)gridDim.x * blockDim.x) {
+    float v[PER];
+    Chunk<T>::load(in + i * PER, v);
+#pragma unroll
+    for (int j = 0; j < PER; ++j) v[j] *= k;
+    Chunk<T>::store(out + i * PER, v);
+  }
+}
+
 // Pseudo labels (see mi355pose.h).  One block per (b,k) map.
 __global__ __launch_bounds__(256) void pseudo_label_kernel(const float* __restrict__ xy, const float* __restrict__ patch, int radius, int div,
                                                             int S, int kind, const float* __restrict__ extra, int normalise,
@@ -213,6 +227,19 @@ extern "C" int mi355_scale_by_dev(const float* in, const float* g_dev, float* ou
   int grid = (int)((n + 255) / 256); if (grid > 4096) grid = 4096;
   hipLaunchKernelGGL(scale_by_dev_kernel, dim3(grid), dim3(256), 0, as_stream(stream), in, g_dev, out, n);
   MI_CHECK_LAUNCH("scale_by_dev");
+  return MI355_OK;
+}
+extern "C" int mi355_scale_feature(const void* in, const float* g_dev, void* out, long n, int dtype, void* stream) {
+  const int per = dtype == MI355_BF16 ? 8 : 4;
+  if (!in || !out || !g_dev || n < 1 || (dtype != MI355_BF16 && dtype != MI355_F32) || n % per)
+    MI_FAIL(MI355_EINVAL, "scale_feature: bad args (n=%ld dtype=%d)", n, dtype);
+  const long nvec = n / per;
+  int grid = (int)((nvec + 255) / 256); if (grid > 8192) grid = 8192;
+  if (dtype == MI355_BF16)
+    hipLaunchKernelGGL(scale_feature_kernel<bf16_t>, dim3(grid), dim3(256), 0, as_stream(stream), (const bf16_t*)in, g_dev, (bf16_t*)out, nvec);
+  else
+    hipLaunchKernelGGL(scale_feature_kernel<float>, dim3(grid), dim3(256), 0, as_stream(stream), (const float*)in, g_dev, (float*)out, nvec);
+  MI_CHECK_LAUNCH("scale_feature");
   return MI355_OK;
 }
 extern "C" int mi355_pseudo_label(const float* xy, const float* patch, int radius, int div, int S, int kind, const float* extra,

@@ -73,6 +73,7 @@ SIGNATURES = {
     'mi355_kl_heatmap': (_I, [_P, _P, _P, _F, _P, _P, _I, _I, _F, _P]),
     'mi355_reduce_sum': (_I, [_P, _P, _I, _F, _P]),
     'mi355_scale_by_dev': (_I, [_P, _P, _P, _L, _P]),
+    'mi355_scale_feature': (_I, [_P, _P, _P, _L, _I, _P]),
     'mi355_pseudo_label': (_I, [_P, _P, _I, _I, _I, _I, _P, _I, _P, _P, _I, _I, _P]),
     'mi355_bilinear_up': (_I, [_P, _P, _I, _I, _I, _I, _I, _F, _I, _P]),
     'mi355_pck_dists': (_I, [_P, _P, _P, _I, _F, _F, _P]),

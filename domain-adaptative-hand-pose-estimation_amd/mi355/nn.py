@@ -20,6 +20,7 @@ from . import ops
 # ---------------------------------------------------------------- parameter-gradient bookkeeping
 def grad_slot(p):
     """Return (tensor to write the gradient into, accumulate?) for parameter `p`."""
+    p._mi_slot = True              # this gradient is written by the kernels, not by autograd's AccumulateGrad
     if p.grad is None:
         p.grad = torch.empty_strided(p.shape, p.stride(), dtype=p.dtype, device=p.device)
         p._mi_fresh = False
@@ -151,12 +152,26 @@ def _dgrad_for_bn(desc, dy, wt, src, x_in, scale_dev=None, out=None, accumulate=
     return dx
 
 
+def _claim_gl(x, dtype):
+    """(autograd input, lambda scalar) for a conv whose input may be the alias returned by WarmStartGradientLayer.
+    The conv folds lambda into its own dgrad epilogue, so it takes the layer's INPUT as autograd input (same memory):
+    its gradient bypasses the layer's scaling Function.  Anything that is not a ready feature tensor is left alone and
+    goes through that Function (correct, one extra kernel)."""
+    tag = getattr(x, '_mi_gl', None)
+    if tag is None:
+        return x, None
+    src, scale = tag
+    if ops.is_nhwc(src) and src.dtype == dtype and src.data_ptr() == x.data_ptr() and src.shape == x.shape:
+        return src, scale
+    return x, None
+
+
 def _take_partial(mod, y):
     """Move the statistics partials a conv's forward left on its module onto the output tensor (read by BatchNorm2d)."""
     part = mod._last_partial
     if part is not None:
         mod._last_partial = None
-        y._mi_bn_partial = part
+        y._mi_bn_partial = (part, y._version)      # the version makes an in-place edit of y before the BatchNorm visible
     return y
 
 
@@ -513,7 +528,9 @@ class Conv2d(nn.Module):
     def forward(self, x, residual=None):
         dtype = compute_dtype()
         mode = self.mode
-        scale = getattr(x, '_mi_grad_scale', None)
+        scale = None
+        if mode != 'k2c':
+            x, scale = _claim_gl(x, dtype)
         if mode == 'c2k':
             x = _as_feature(x, dtype)
             return _PwC2KFn.apply(x, self.weight, self.bias, scale, self)
@@ -533,7 +550,7 @@ class Conv2d(nn.Module):
 
     def forward_skip(self, x):
         """(conv(x), alias of x): for residual blocks, see _ConvSkipFn.  Bias-free MFMA convs only."""
-        if not _SKIP_FUSE or self.mode != 'mfma' or self.bias is not None or getattr(x, '_mi_grad_scale', None) is not None or \
+        if not _SKIP_FUSE or self.mode != 'mfma' or self.bias is not None or getattr(x, '_mi_gl', None) is not None or \
                 self.in_channels != self._cin_pad(compute_dtype()):
             return self.forward(x), x
         x = _as_feature(x, compute_dtype())
@@ -596,9 +613,15 @@ class BatchNorm2d(nn.Module):
     def forward(self, x, residual=None, relu=False):
         x = _as_feature(x, compute_dtype())
         if self.training:
-            partial = getattr(x, '_mi_bn_partial', None)      # statistics partials from the conv that produced x
-            if partial is not None and (x.shape[1] != self.num_features or not ops.is_nhwc(x)):
-                partial = None
+            tag = getattr(x, '_mi_bn_partial', None)          # statistics partials from the conv that produced x
+            partial = None
+            if tag is not None:
+                partial, ver = tag
+                if x._version != ver:
+                    raise Mi355Error('the conv output was modified in place before its BatchNorm: the statistics fused into '
+                                     'the conv epilogue are stale (use an out-of-place op, or set MI355_BN_STATS_FUSE=0)')
+                if x.shape[1] != self.num_features or not ops.is_nhwc(x):
+                    partial = None
             y = _BnFn.apply(x, self.weight, self.bias, residual, self, bool(relu), partial)
             y._mi_bn_src, self._last_src = self._last_src, None     # lets the consumer conv's dgrad reduce dy for this BN
             return y
@@ -632,7 +655,8 @@ def link_conv_bn(module):
     """Mark every conv / deconv child that is directly followed (in registration order) by a BatchNorm2d child: in training
     mode such a conv computes the BatchNorm statistics of its output in its epilogue.  Only a hint -- the BatchNorm uses the
     partials solely when they arrive attached to the very tensor it normalises (``y._mi_bn_partial``); a conv output that is
-    modified in place before it reaches the BatchNorm would carry stale statistics -- the model never does that."""
+    modified in place before it reaches the BatchNorm would carry stale statistics: BatchNorm2d compares the tensor's
+    autograd version with the one recorded by the conv and raises."""
     kids = list(module.children())
     for a, b in zip(kids, kids[1:]):
         if isinstance(a, (Conv2d, ConvTranspose2d)) and isinstance(b, BatchNorm2d):

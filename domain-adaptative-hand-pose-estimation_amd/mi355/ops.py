@@ -348,6 +348,20 @@ def scale_by_dev(t, g_dev):
     return out
 
 
+def scale_feature(t, g_dev):
+    """t * (*g_dev) for a dense fp32 / bf16 device tensor of any layout (same strides out)."""
+    if not t.is_cuda:
+        raise Mi355Error('mi355 ops need CUDA/HIP tensors; there is no CPU fallback')
+    if not (t.is_contiguous() or t.is_contiguous(memory_format=torch.channels_last)):
+        t = t.contiguous()
+    per = 8 if t.dtype == torch.bfloat16 else 4
+    if t.numel() % per:
+        raise Mi355Error('scale_feature needs a multiple of %d elements, got %d' % (per, t.numel()))
+    out = torch.empty_like(t)
+    call('mi355_scale_feature', ptr(t), ptr(g_dev), ptr(out), t.numel(), dtype_code(t.dtype), stream_ptr())
+    return out
+
+
 def pseudo_label(xy, patch, radius, div, S, kind, extra=None, normalise=False, want_gt=True, want_gf=True):
     B, K, _ = xy.shape
     dev = xy.device

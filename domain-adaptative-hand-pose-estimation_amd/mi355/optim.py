@@ -108,9 +108,31 @@ class FusedSGD(Optimizer):
 
     # ------------------------------------------------------------ torch.optim API
     def zero_grad(self, set_to_none=False):
-        """Gradients are overwritten by the next backward (no memset, buffers stay in place)."""
+        """torch.optim.SGD.zero_grad(set_to_none=True) semantics without freeing anything: a parameter that receives no
+        gradient before the next step() is skipped by it (no weight decay, no momentum update), exactly like a parameter
+        whose ``grad is None``.  Gradients written by the mi355 kernels are simply overwritten by the next backward (no
+        memset, the flat buffers stay in place); gradients accumulated by autograd itself (torch-native modules in the
+        same optimizer) are zeroed here and recognised as untouched by their version counter."""
         for group in self.param_groups:
-            mark_grads_fresh(group['params'])
+            ps = group['params']
+            mark_grads_fresh([p for p in ps if getattr(p, '_mi_slot', False)])
+            for p in ps:
+                if p.grad is not None and not getattr(p, '_mi_slot', False):
+                    p.grad.zero_()
+                    p._mi_zero_ver = p.grad._version
+
+    @staticmethod
+    def _stale(p):
+        """True when `p` received no gradient since the last zero_grad()."""
+        if getattr(p, '_mi_slot', False):
+            return bool(getattr(p, '_mi_fresh', False))
+        return p.grad is not None and getattr(p, '_mi_zero_ver', None) == p.grad._version
+
+    def _late_params(self):
+        """Parameters that own a gradient now but did not when the flat buffers were laid out."""
+        known = {i for f in self._flat if f is not None for i in f['offs']}
+        return [p for g in self.param_groups for p in g['params']
+                if p.requires_grad and p.grad is not None and id(p) not in known]
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -120,15 +142,39 @@ class FusedSGD(Optimizer):
                 loss = closure()
         _rt.join_side()              # weight gradients computed on the side stream must have landed
         self.ensure_flat()
+        if self._late_params():      # first gradient arrived after the flat layout was fixed: lay it out again
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError('FusedSGD: a parameter received its first gradient during graph capture; run one eager '
+                                   'step with every parameter active before capturing')
+            self._flat = None
+            self.ensure_flat()
         if not torch.cuda.is_current_stream_capturing():
             self.sync_lr()
         for f in self._flat:
             if f is None:
                 continue
             g = self.param_groups[f['gi']]
-            ops.sgd_nesterov(f['P'], f['G'], f['M'], f['lr_dev'], g['momentum'], g['weight_decay'], g['nesterov'])
-            for p in f['params']:
-                p._mi_epoch = getattr(p, '_mi_epoch', 0) + 1
+            stale = [self._stale(p) for p in f['params']]
+            if not any(stale):
+                runs = [(0, f['P'].numel())]
+            else:                    # step the contiguous runs of parameters that did receive a gradient
+                runs, lo = [], None
+                for p, st in zip(f['params'], stale):
+                    o, n = f['offs'][id(p)]
+                    if st:
+                        if lo is not None:
+                            runs.append((lo, o))
+                            lo = None
+                    elif lo is None:
+                        lo = o
+                if lo is not None:
+                    runs.append((lo, f['P'].numel()))
+            for lo, hi in runs:
+                ops.sgd_nesterov(f['P'][lo:hi], f['G'][lo:hi], f['M'][lo:hi], f['lr_dev'], g['momentum'], g['weight_decay'],
+                                 g['nesterov'])
+            for p, st in zip(f['params'], stale):
+                if not st:
+                    p._mi_epoch = getattr(p, '_mi_epoch', 0) + 1
             repack_params(f['params'], f.setdefault('pack_cache', {}))     # packed conv copies: one launch per group
         return loss
 

@@ -23,16 +23,15 @@ from utils.logger import CompleteLogger
 
 
 def main(args):
-    logger = CompleteLogger(args.log, 'test')
+    T.init_distributed()
+    logger = CompleteLogger(args.log, 'test', quiet=T.RANK != 0)
     print(args)
     if T.device.type != 'cuda':
         raise SystemExit('this evaluation path needs an MI355X (HIP kernels only, no CPU fallback)')
     mi355.load()
     mi355.set_compute_dtype(args.dtype)
     _, val_s, _, val_t = T.build_datasets(args)
-    from torch.utils.data import DataLoader
-    val_source_loader = DataLoader(val_s, batch_size=args.batch_size, shuffle=False, pin_memory=True)
-    val_target_loader = DataLoader(val_t, batch_size=args.batch_size, shuffle=False, pin_memory=True)
+    val_source_loader, val_target_loader = T.make_loader(val_s, args, False), T.make_loader(val_t, args, False)
     backbone = models.__dict__[args.arch](pretrained=False)
     model = PoseResNetx9(backbone, Upsampling(backbone.out_features), 256, val_s.num_keypoints,
                          num_head_layers=args.num_head_layers, finetune=True).to(T.device)

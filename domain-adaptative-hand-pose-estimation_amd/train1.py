@@ -5,6 +5,16 @@ validate :495-536, CLI :591-675).  Additive flags: ``--synthetic`` (seeded synth
 out-of-scope CPU dataset layer), ``--dtype {bf16,f32}``, ``--no-graph``.
 
     python train1.py data/H3D -t Hand3DStudio --synthetic -a resnet50 -b 64
+
+Data parallel (the reference is single-process): start one process per GPU with torchrun,
+
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 train1.py data/H3D ... -b 64
+
+``-b`` stays the per-GPU batch (the path shards by image, BatchNorm statistics stay per GPU as in the reference).  Every
+rank reads ``RANK / LOCAL_RANK / WORLD_SIZE`` before touching the GPU, draws its own shard of both training sets
+(``DistributedSampler``), the gradient mean of the optimizers about to step is exchanged over RCCL (``mi355.da_step``),
+validation counts are summed over ranks, and only rank 0 writes the log and the checkpoints (reference sites made
+rank-aware: train1.py:54-99 loaders, :141-154 optimizers, :248-268 checkpoints).
 """
 import argparse
 import os
@@ -19,12 +29,14 @@ if HERE not in sys.path:
     sys.path.insert(0, HERE)
 
 import torch
+import torch.distributed as dist
 from torch.optim.lr_scheduler import LambdaLR, MultiStepLR
 from torch.utils.data import DataLoader
+from torch.utils.data.distributed import DistributedSampler
 
 import mi355
 import uda.model as models
-from mi355.da_step import build_training
+from mi355.da_step import build_training, broadcast_module, _allreduce_mean
 from mi355.optim import FusedSGD
 from uda.model.loss import JointsKLLoss
 from uda.model.pose_resnet2 import Upsampling, PoseResNet
@@ -34,7 +46,39 @@ from utils.keypoint_detection import accuracy
 from utils.logger import CompleteLogger
 from utils.meter import AverageMeter, ProgressMeter, AverageMeterDict
 
-device = torch.device("cuda" if torch.cuda.is_available() else "cpu")
+device = torch.device("cuda" if torch.cuda.device_count() > 0 else "cpu")     # device_count() does not initialise the GPU
+RANK, WORLD = 0, 1
+
+
+def init_distributed():
+    """One process per GPU: read the torchrun environment BEFORE any GPU call, bind this process to its GPU and join
+    the process group (backend nccl = RCCL over xGMI; MI355_DIST_BACKEND=gloo for rehearsals with several ranks on
+    one GPU).  Single-process runs (no WORLD_SIZE) skip all of it."""
+    global device, RANK, WORLD
+    WORLD = int(os.environ.get('WORLD_SIZE', '1'))
+    RANK = int(os.environ.get('RANK', '0'))
+    if WORLD > 1:
+        local = int(os.environ.get('LOCAL_RANK', str(RANK)))
+        ndev = torch.cuda.device_count()
+        if ndev == 0:
+            raise SystemExit('this training path needs an MI355X (HIP kernels only, no CPU fallback)')
+        torch.cuda.set_device(local % ndev)
+        device = torch.device('cuda', local % ndev)
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group(os.environ.get('MI355_DIST_BACKEND', 'nccl'), rank=RANK, world_size=WORLD)
+    return RANK, WORLD
+
+
+def replicas_in_sync(model):
+    """Failure detection for the data-parallel run: every rank must hold bit-identical parameters (same initial
+    broadcast, same averaged gradients, same deterministic update kernels).  Returns the checksum, raises on drift."""
+    cs = torch.stack([p.detach().double().abs().sum() for p in model.parameters()]).sum().reshape(1)
+    if WORLD > 1:
+        every = [torch.zeros_like(cs) for _ in range(WORLD)]
+        dist.all_gather(every, cs)
+        if any(float(e) != float(every[0]) for e in every):
+            raise RuntimeError('data-parallel replicas diverged: parameter checksums %s' % [float(e) for e in every])
+    return float(cs)
 
 
 def build_datasets(args):
@@ -61,21 +105,35 @@ def build_datasets(args):
             tgt(root=args.target_root, transforms=train_tf, **kw), tgt(root=args.target_root, split='test', transforms=val_tf, **kw))
 
 
+def make_loader(ds, args, train):
+    """train: this rank's shard (reshuffled every pass, ForeverDataIterator advances the sampler epoch); validation: the
+    strided shard rank::WORLD without padding, so that the counts summed over ranks are exactly the data set's."""
+    if WORLD == 1:
+        return DataLoader(ds, batch_size=args.batch_size, shuffle=train, num_workers=args.workers if train else 0,
+                          pin_memory=True, drop_last=train)
+    if train:
+        sampler = DistributedSampler(ds, num_replicas=WORLD, rank=RANK, shuffle=True, seed=args.seed or 0, drop_last=True)
+        return DataLoader(ds, batch_size=args.batch_size, sampler=sampler, num_workers=args.workers, pin_memory=True, drop_last=True)
+    return DataLoader(ds, batch_size=args.batch_size, sampler=list(range(RANK, len(ds), WORLD)), num_workers=0, pin_memory=True)
+
+
 def main(args):
-    logger = CompleteLogger(args.log, args.phase)
+    init_distributed()
+    logger = CompleteLogger(args.log, args.phase, quiet=RANK != 0)      # rank 0 owns the console mirror and the log file
     print(args)
     if device.type != 'cuda':
         raise SystemExit('this training path needs an MI355X (HIP kernels only, no CPU fallback)')
     mi355.load()
     mi355.set_compute_dtype(args.dtype)
     if args.seed is not None:
-        random.seed(args.seed)
-        torch.manual_seed(args.seed)
+        random.seed(args.seed + RANK)
+        torch.manual_seed(args.seed)             # same initial weights everywhere (and broadcast below anyway)
         warnings.warn('You have chosen to seed training.')
+    if WORLD > 1:
+        print('data parallel: %d ranks, backend %s, per-GPU batch %d' % (WORLD, dist.get_backend(), args.batch_size))
 
     train_s, val_s, train_t, val_t = build_datasets(args)
-    ld = lambda ds, train: DataLoader(ds, batch_size=args.batch_size, shuffle=train, num_workers=args.workers if train else 0,
-                                      pin_memory=True, drop_last=train)
+    ld = lambda ds, train: make_loader(ds, args, train)
     train_source_loader, val_source_loader = ld(train_s, True), ld(val_s, False)
     train_target_loader, val_target_loader = ld(train_t, True), ld(val_t, False)
     print("Source train:", len(train_source_loader)); print("Target train:", len(train_target_loader))
@@ -121,8 +179,11 @@ def main(args):
                 acc = validate(val_source_loader, pre, criterion, args)
                 if acc['all'] > best_acc:
                     best_acc = acc['all']
-                    torch.save({'model': pre.state_dict()}, args.pretrain)
+                    if RANK == 0:
+                        torch.save({'model': pre.state_dict()}, args.pretrain)
                 print("Source: {} best: {}".format(acc['all'], best_acc))
+            if WORLD > 1:
+                dist.barrier()                           # rank 0 has written the file everybody reads next
         pretrained_dict = torch.load(args.pretrain, map_location='cpu', weights_only=False)['model']
         model_dict = model.state_dict()
         pretrained_dict = {k: v for k, v in pretrained_dict.items() if k in model_dict}
@@ -138,6 +199,8 @@ def main(args):
                 opts[k].load_state_dict(ck['optimizer_' + k]); scheds[k].load_state_dict(ck['lr_scheduler_' + k])
         model.gl_layer.iter_num = ck.get('gl_iter_num', 0)
         start_epoch = ck['epoch'] + 1
+    broadcast_module(model)                              # replicas start bit-identical whatever each rank loaded
+    broadcast_module(model_ema)
 
     if args.phase == 'test':
         s_acc = validate(val_source_loader, model, criterion, args)
@@ -156,6 +219,13 @@ def main(args):
         train(train_source_iter, train_target_iter, step, scheds, epoch, args)
         s_acc = validate(val_source_loader, model, criterion, args)
         t_acc = validate(val_target_loader, model, criterion, args)
+        if WORLD > 1:
+            print('replicas in sync (parameter checksum %.6e)' % replicas_in_sync(model))
+        if RANK != 0:
+            if WORLD > 1:
+                dist.barrier()
+            best_acc = max(best_acc, t_acc['all'])
+            continue
         torch.save({'model': model.state_dict(),
                     'optimizer_f': opts['f'].state_dict(), 'optimizer_h': opts['h'].state_dict(),
                     'optimizer_h_adv': opts['h_adv'].state_dict(),
@@ -169,10 +239,14 @@ def main(args):
         if t_acc['all'] > best_acc:
             shutil.copy(logger.get_checkpoint_path(epoch), logger.get_checkpoint_path('best'))
             best_acc = t_acc['all']
+        if WORLD > 1:
+            dist.barrier()                               # checkpoints of this epoch are complete
         print("Source: {:4.3f} Target: {:4.3f} Target(best): {:4.3f}".format(s_acc['all'], t_acc['all'], best_acc))
         for name, acc in t_acc.items():
             print("{}: {:4.3f}".format(name, acc))
     logger.close()
+    if WORLD > 1:
+        dist.destroy_process_group()
 
 
 def pretrain(train_source_iter, model, criterion, optimizer, epoch, args):
@@ -189,6 +263,8 @@ def pretrain(train_source_iter, model, criterion, optimizer, epoch, args):
         y_s = model(x_s)
         loss_s = criterion(y_s, label_s, weight_s)
         loss_s.backward()
+        if WORLD > 1:
+            _allreduce_mean(optimizer.flat_grads())     # gradient mean over ranks (the flat buffers are the buckets)
         optimizer.step()
         if i % args.print_freq == 0:                    # host reads only when something is printed
             _, avg_acc_s, cnt_s, _ = accuracy(y_s.detach(), label_s)
@@ -217,8 +293,16 @@ def train(train_source_iter, train_target_iter, step, scheds, epoch, args):
         to = lambda t: t.to(device, non_blocking=True)
         batch = dict(x_s=to(x_s), label_s=to(label_s), w_s=to(weight_s), x_t=to(x_t), w_t=to(weight_t), label_t=to(label_t))
         meters[1].update(time.time() - end)
-        if not args.no_graph and step.graphs is None and (epoch, i) == (0, 3):
-            step.capture(batch, warmup=0)
+        # HIP-graph replay once this process has run three eager iterations (whatever epoch it resumed at); with several
+        # ranks the eager path stays: its gradient exchange overlaps the backward, graph replay would serialise it
+        step.eager_iters = getattr(step, 'eager_iters', 0)
+        if step.graphs is None and not args.no_graph and (WORLD == 1 or os.environ.get('MI355_DDP_GRAPH') == '1'):
+            if step.eager_iters == 3:
+                step.capture(batch, warmup=0)
+                print('HIP graphs captured: iterations replay six graphs from here on')
+        elif step.graphs is None and step.eager_iters == 0:
+            print('eager kernel launches%s' % (' with the gradient exchange overlapped with the backward' if WORLD > 1 else ''))
+        step.eager_iters += 1
         out = step.run(batch)                            # steps A, B, C + GL step (train1.py:371-453)
         for s in scheds.values():
             s.step()
@@ -250,6 +334,15 @@ def validate(val_loader, model, criterion, args):
             end = time.time()
             if i % args.print_freq == 0:
                 progress.display(i)
+    if WORLD > 1:                                        # sums and counts over all shards (train1.py:505-524 per shard)
+        keys = list(acc.dict.keys())
+        t = torch.tensor([v for k in keys for v in (acc[k].sum, acc[k].count)] + [losses.sum, losses.count],
+                         dtype=torch.float64, device=device)
+        dist.all_reduce(t)
+        t = t.cpu().tolist()
+        for j, k in enumerate(keys):
+            acc[k].sum, acc[k].count = t[2 * j], t[2 * j + 1]
+            acc[k].avg = acc[k].sum / max(acc[k].count, 1)
     return acc.average()
 
 

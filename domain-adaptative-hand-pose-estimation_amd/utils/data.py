@@ -7,8 +7,13 @@ import torch
 
 def _cycle_fresh(loader):
     # itertools.cycle would replay the cached first epoch; a shuffling loader must be re-iterated instead
+    passes = 0
     while True:
         empty = True
+        sampler = getattr(loader, 'sampler', None)
+        if hasattr(sampler, 'set_epoch'):        # DistributedSampler: a new permutation for every pass over the shard
+            sampler.set_epoch(passes)
+        passes += 1
         for batch in loader:
             empty = False
             yield batch

@@ -26,13 +26,34 @@ class TextLogger:
         self.log.close()
 
 
+class _Null:
+    def write(self, message):
+        pass
+
+    def flush(self):
+        pass
+
+    def close(self):
+        pass
+
+
 class CompleteLogger:
-    def __init__(self, root, phase='train'):
+    """``quiet=True`` (additive; ranks > 0 of a data-parallel run): same directory layout and paths, but ordinary output
+    is dropped instead of being mirrored -- rank 0 owns the console and the log file; stderr stays attached."""
+
+    def __init__(self, root, phase='train', quiet=False):
         self.root, self.phase, self.epoch = root, phase, 0
         self.visualize_directory = os.path.join(root, 'visualize')
         self.checkpoint_directory = os.path.join(root, 'checkpoints')
         for d in (self.visualize_directory, self.checkpoint_directory):
             os.makedirs(d, exist_ok=True)
+        self._saved = (sys.stdout, sys.stderr)
+        if quiet:
+            self.logger = _Null()
+            sys.stdout = self.logger
+            if phase != 'train':
+                self.set_epoch(phase)
+            return
         stamp = time.strftime('%Y-%m-%d-%H_%M_%S')
         path = os.path.join(root, '%s-%s.txt' % (phase, stamp))
         if os.path.exists(path):          # two runs within the same second: start the file afresh

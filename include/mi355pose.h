@@ -208,6 +208,10 @@ int mi355_kl_heatmap(const float* pred, const float* target, const float* weight
 int mi355_reduce_sum(const float* in, float* out, int n, float scale, void* stream);
 /* out[i] = in[i] * (*g_dev) : backward of the KL loss (upstream scalar gradient on device). */
 int mi355_scale_by_dev(const float* in, const float* g_dev, float* out, long n, void* stream);
+/* out[i] = in[i] * (*g_dev) on a feature tensor (dtype MI355_F32 / MI355_BF16, n a multiple of one 16-byte chunk):
+ * backward of utils/gl.py:8-18 (GradientFunction: grad * coeff) for consumers that cannot fold lambda into their own
+ * input-gradient epilogue. */
+int mi355_scale_feature(const void* in, const float* g_dev, void* out, long n, int dtype, void* stream);
 /* Pseudo labels from arg-max coordinates xy[B*K][2] (of the 64x64-level main prediction):
  *   centre = trunc(xy / div); gt = clipped Gaussian patch (patch[(2r+1)^2], host table) at centre on an
  *   S x S map.  regda_4.py:76-86 (div 1, r 6), regda_7.py:3026-3039 (div 4, r 3), :3188-3201 (div 2, r 4).

@@ -45,7 +45,7 @@ import uda.model.loss as ref_loss  # noqa: E402
 import uda.model.regda_4 as ref_r4  # noqa: E402
 import uda.model.regda_7 as ref_r7  # noqa: E402
 import uda.model.pose_resnet2 as ref_pr2  # noqa: E402
-from seeded import fill_module_, randn, rand, peaky_heatmaps, weights_bk  # noqa: E402
+from seeded import fill_module_, randn, rand, peaky_heatmaps, weights_bk, g9_inputs  # noqa: E402
 
 torch.set_num_threads(8)
 
@@ -229,9 +229,133 @@ def g7_iteration():
     save('g7_iteration', **res)
 
 
+def _ref_da_model(arch, seed):
+    from oracle.backbone import make_backbone
+    bb = make_backbone(arch)
+    model = ref_r7.PoseResNetx9(bb, ref_pr2.Upsampling(bb.out_features), 256, 21, num_head_layers=2, finetune=True)
+    fill_module_(model, seed)
+    return bb, model
+
+
+def _g8_iteration(dt):
+    from torch.optim import SGD
+    from torch.optim.lr_scheduler import LambdaLR
+    bb, model = _ref_da_model('resnet50', 801)
+    model = model.to(dt)
+    B = 2
+    x_s, x_t = randn(802, B, 3, 256, 256).to(dt), randn(8034, B, 3, 256, 256).to(dt)
+    label_s = (rand(804, B, 21, 64, 64) * (rand(805, B, 21, 64, 64) > 0.9)).to(dt)
+    w_s, w_t = weights_bk(806, B, 21).to(dt), weights_bk(807, B, 21).to(dt)
+    criterion = ref_loss.JointsKLLoss()
+    kl = lambda: ref_loss.JointsKLLoss(epsilon=1e-7)
+    rd = ref_r7.RegressionDisparityx6(ref_r4.PseudoLabelGenerator(21, 64, 64), kl())
+    rd2 = ref_r7.RegressionDisparityx5(ref_r7.PseudoLabelGenerator03(21), kl())
+    rd1 = ref_r7.RegressionDisparityx1(ref_r7.PseudoLabelGenerator01(21), kl())
+    mk = lambda ps: SGD(ps, lr=0.1, momentum=0.9, weight_decay=1e-4, nesterov=True)
+    of = mk([{'params': bb.parameters(), 'lr': 0.1}, {'params': model.upsampling.parameters(), 'lr': 0.1}])
+    oh, oa, oa2, oa3 = (mk(getattr(model, n).parameters()) for n in ('head', 'head_adv', 'head_adv2', 'head_adv3'))
+    opts = [of, oh, oa, oa2, oa3]
+    scheds = [LambdaLR(o, lambda x: 0.01 * (1. + 1e-4 * float(x)) ** (-0.75)) for o in opts]
+    model.gl_layer.iter_num = 500
+    model.train()
+    res = {}
+    for o in opts:
+        o.zero_grad()
+    y_s, y_s_adv, y_s_adv2, y_s_adv3, f_s = model(x_s)
+    res.update(y_s=y_s[:, ::5].detach().clone(), y_s_adv=y_s_adv[:, ::5].detach().clone(),
+               y_s_adv2=y_s_adv2[:, ::5].detach().clone(), y_s_adv3=y_s_adv3[:, ::5].detach().clone(),
+               f_slice=f_s[:, :8, :16, :16].detach().clone(), f_abs=f_s.detach().double().abs().sum())
+    loss_s = 2 * criterion(y_s, label_s, w_s) + 4 * rd2(y_s, y_s_adv2, None, w_s, mode='min') + \
+        4 * rd(y_s, y_s_adv, None, w_s, mode='min') + 4 * rd1(y_s, y_s_adv3, w_s, mode='min')
+    loss_s.backward()
+    gkeys = sorted(k for k, p in model.named_parameters() if p.grad is not None)
+    res['gradA_keys'] = np.array(gkeys)
+    gp = dict(model.named_parameters())
+    res['gradA_norm'] = np.array([float(gp[k].grad.double().norm()) for k in gkeys])
+    res['gradA_sum'] = np.array([float(gp[k].grad.double().sum()) for k in gkeys])
+    for o in opts:
+        o.step()
+    for o in (oa, oa2, oa3):
+        o.zero_grad()
+    y_t, y_t_adv, y_t_adv2, y_t_adv3, f_t = model(x_t)
+    l1 = rd1(y_t, y_t_adv3, w_t, mode='max')
+    t = nn.Upsample(size=64, mode='bilinear')(y_t_adv3.detach())
+    t1 = nn.Upsample(size=64, mode='bilinear')(y_t_adv2.detach())
+    t0 = nn.Upsample(size=32, mode='bilinear')(y_t_adv3.detach())
+    l2 = rd(y_t, y_t_adv, 0.5 * t + t1, w_t, mode='max')
+    l3 = rd2(y_t, y_t_adv2, t0, w_t, mode='max')
+    loss_gf = 0.3 * l1 + 1 * l2 + 0.3 * l3
+    loss_gf.backward()
+    oa2.step(); oa.step(); oa3.step()
+    of.zero_grad()
+    y_t, y_t_adv, y_t_adv2, y_t_adv3, f_t = model(x_t)
+    loss_gt = 0.3 * rd2(y_t, y_t_adv2, None, w_t, mode='min') + 1 * rd(y_t, y_t_adv, None, w_t, mode='min')
+    loss_gt.backward()
+    of.step()
+    model.step()
+    for s in scheds:
+        s.step()
+    res["losses"] = np.array([float(v.detach()) for v in (loss_s, loss_gf, loss_gt)], dtype=np.float64)
+    sd = model.state_dict()
+    keys = sorted(k for k in sd if not k.endswith('num_batches_tracked'))
+    res['param_sum'] = np.array([float(sd[k].double().sum()) for k in keys])
+    res['param_abs'] = np.array([float(sd[k].double().abs().sum()) for k in keys])
+    res['param_keys'] = np.array(keys)
+    res['nbt_layer4'] = np.array(int(sd['backbone.layer4.2.bn3.num_batches_tracked']))
+    return res
+
+
+def g8_bottleneck():
+    """The benchmarked architectures (Bottleneck nets, uda/model/resnet.py:92-107): one complete A/B/C iteration of
+    train1.py:371-458 over the reference's PoseResNetx9 + loss classes on a ResNet-50 layout (B=2, 256x256, fp32):
+    5-tuple slices of the step-A forward, per-parameter gradient norms of step A, the three losses, every parameter's
+    sum and |sum| after the iteration.  The same run in fp64 (keys *64) is the yardstick for the quantities that sit
+    behind an SGD update: gradients of this random-init network are ill-conditioned (fp32 vs fp64 of the reference's
+    own classes: ~1e-2 relative per parameter), so losses of steps B / C differ by ~1e-3 between any two
+    implementations.  Plus a ResNet-101 train-mode forward (slices + BN running statistics of the deepest stages)."""
+    res = _g8_iteration(torch.float32)
+    r64 = _g8_iteration(torch.float64)
+    assert list(r64['gradA_keys']) == list(res['gradA_keys'])
+    res.update(losses64=r64['losses'], gradA_norm64=r64['gradA_norm'], param_abs64=r64['param_abs'])
+    B = 2
+    # ResNet-101: train-mode forward only; the fp64 run of the same classes is the yardstick (B=2 batch statistics over
+    # 128 samples per channel in layer4 make the deep train-mode forward itself sensitive: fp32 vs fp64 2e-3 at y_adv3)
+    for dt, sfx in ((torch.float32, ''), (torch.float64, '64')):
+        bb, m101 = _ref_da_model('resnet101', 811)
+        m101 = m101.to(dt).train()
+        x = randn(812, B, 3, 256, 256).to(dt)
+        with torch.no_grad():
+            y, y_adv, y_adv2, y_adv3, f = m101(x)
+        sd = m101.state_dict()
+        res.update({'r101_y' + sfx: y[:, ::5].clone(), 'r101_y_adv3' + sfx: y_adv3[:, ::5].clone(),
+                    'r101_f_slice' + sfx: f[:, :8, :16, :16].clone(), 'r101_f_abs' + sfx: f.double().abs().sum(),
+                    'r101_rm' + sfx: sd['backbone.layer3.22.bn3.running_mean'].clone(),
+                    'r101_rv' + sfx: sd['backbone.layer4.2.bn3.running_var'].clone()})
+        if dt == torch.float32:
+            m101.eval()
+            with torch.no_grad():
+                res['r101_y_eval'] = m101(x)[:, ::5].clone()
+    save('g8_bottleneck', **res)
+
+
+
+def g9_generate_target():
+    """uda/dataset/util.py:9-68 run on the reference itself (cv2 / scipy.io are import-only there: cv2 is stubbed)."""
+    _stub('cv2')
+    _stub('uda.dataset', f'{REF}/uda/dataset')
+    import uda.dataset.util as ref_util
+    kp, vis = g9_inputs()
+    out = {}
+    for tag, (hm, img) in dict(a=((64, 64), (256, 256)), b=((32, 32), (128, 128)), c=((128, 128), (512, 512))).items():
+        scale = img[0] / 256.0
+        t, w = zip(*[ref_util.generate_target(kp[b] * scale, vis[b], hm, 2, img) for b in range(kp.shape[0])])
+        out['target_' + tag], out['weight_' + tag] = np.stack(t), np.stack(w)
+    save('g9_generate_target', **out)
+
+
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['g1', 'g2', 'g3', 'g4', 'g5', 'g6', 'g7']
+    which = sys.argv[1:] or ['g1', 'g2', 'g3', 'g4', 'g5', 'g6', 'g7', 'g8', 'g9']
     fns = {'g1': g1_neck_heads, 'g2': g2_losses, 'g3': g3_pseudo_labels, 'g4': g4_argmax_accuracy,
-           'g5': g5_softargmax, 'g6': g6_gl, 'g7': g7_iteration}
+           'g5': g5_softargmax, 'g6': g6_gl, 'g7': g7_iteration, 'g8': g8_bottleneck, 'g9': g9_generate_target}
     for w in which:
         fns[w]()

@@ -64,3 +64,18 @@ def weights_bk(seed, B, K):
     rng = np.random.default_rng(seed)
     w = (rng.random((B, K, 1)) > 0.15).astype(np.float32)
     return torch.from_numpy(w)
+
+
+def g9_inputs():
+    """Joint sets for the label-generation fixture: interior, on / across every border, far outside, invisible."""
+    rng = np.random.default_rng(901)
+    B, K = 4, 21
+    kp = rng.uniform(-14, 270, size=(B, K, 2))
+    kp[0, 0] = (0.0, 0.0); kp[0, 1] = (255.9, 255.9); kp[0, 2] = (3.9, 250.0); kp[0, 3] = (258.0, 10.0)
+    kp[0, 4] = (-1.9, 100.0); kp[0, 5] = (-2.1, 100.0); kp[0, 6] = (253.9, 254.0); kp[0, 7] = (254.0, 1.9)
+    kp[1, 0] = (128.0, 128.0); kp[1, 1] = (130.0, 126.0); kp[1, 2] = (1.99, 2.0); kp[1, 3] = (2.0, 1.99)
+    kp[1, 4] = (12.0, 243.9); kp[1, 5] = (243.9, 12.0); kp[1, 6] = (500.0, 500.0); kp[1, 7] = (-300.0, 20.0)
+    vis = (rng.random((B, K, 1)) < 0.8).astype(np.float32)
+    vis[0, :8] = 1.0
+    vis[1, 0] = 0.0
+    return kp, vis

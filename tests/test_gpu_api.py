@@ -149,3 +149,103 @@ def test_device_prefetcher_stages_batches_in_order(gpu):
     assert seq == [0, 1, 2, 0, 1, 2, 0, 1]
     with pytest.raises(ValueError):
         DevicePrefetcher(iter(host), 'cpu')
+
+
+@pytest.mark.parametrize('dt', ['f32', 'bf16'])
+def test_gradient_layer_scales_whatever_consumes_it(gpu, dt):
+    """utils/gl.py:8-18: backward = grad * coeff for EVERY consumer of the layer's output.  The mi355 convs fold lambda
+    into their dgrad epilogue (no kernel); a consumer that hides the output behind another op (clone, arithmetic, a
+    foreign module) must still see the scaled gradient: direct conv, clone -> conv, mixed fan-out and a plain torch
+    consumer all give lambda * (unscaled gradient)."""
+    import mi355
+    from mi355.nn import Conv2d
+    from utils.gl import WarmStartGradientLayer
+    mi355.set_compute_dtype(dt)
+    tdt = mi355.compute_dtype()
+    tol = 1e-5 if dt == 'f32' else 2e-2
+    conv = Conv2d(16, 16, 3, 1, 1, bias=False).to(gpu)
+    conv2 = Conv2d(16, 24, 1, 1, 0, bias=True).to(gpu)
+    fill_module_(conv, 41); fill_module_(conv2, 42)
+    gl = WarmStartGradientLayer(alpha=1.0, lo=0.0, hi=0.1, max_iters=1000, auto_step=False)
+    gl.iter_num = 700
+    lam = gl.coeff
+    assert 0.03 < lam < 0.04
+    x0 = randn(43, 2, 16, 12, 12).to(gpu).to(tdt).contiguous(memory_format=torch.channels_last)
+    wsum = randn(44, 2, 16, 12, 12).to(gpu)
+
+    def grad_of(fn):
+        x = x0.clone().requires_grad_(True)
+        fn(x).backward()
+        return x.grad.float()
+
+    loss = lambda y: (y.float() * wsum[:, :y.shape[1]].expand_as(y) if y.shape[1] <= 16 else y.float()).sum()
+    base1 = grad_of(lambda x: loss(conv(x)))                       # no gradient layer
+    base2 = grad_of(lambda x: loss(conv(x)) + loss(conv2(x)))
+    scale = float(base2.abs().max())
+    direct = grad_of(lambda x: loss(conv(gl(x))))                  # folded into the dgrad epilogue
+    cloned = grad_of(lambda x: loss(conv(gl(x).clone())))          # tag lost: the layer's own backward scales
+    mixed = grad_of(lambda x: (lambda f: loss(conv(f)) + loss(conv2(f * 1.0)))(gl(x)))   # one claims, one does not
+    plain = grad_of(lambda x: (gl(x).float() * wsum).sum())        # pure torch consumer
+    for name, got, ref in (('direct', direct, lam * base1), ('clone', cloned, lam * base1), ('mixed', mixed, lam * base2),
+                           ('plain', plain, lam * wsum)):
+        err = float((got - ref).abs().max())
+        assert err <= tol * lam * max(scale, 1.0), '%s: %.3e' % (name, err)
+    # forward is an alias (no copy), like the tagged path it replaces
+    x = x0.clone().requires_grad_(True)
+    assert gl(x).data_ptr() == x.data_ptr()
+
+
+def test_fused_sgd_is_a_drop_in_for_torch_sgd(gpu):
+    """torch.optim.SGD semantics in the corner cases the A/B/C loop never hits: a parameter that receives no gradient
+    between zero_grad() and step() is skipped (torch: grad None), a parameter whose first gradient arrives after the
+    flat buffers were laid out is picked up, and gradients accumulated by autograd itself (torch-native module) work."""
+    from mi355.nn import Conv2d
+    from mi355.optim import FusedSGD
+    import mi355.nn as mnn
+
+    def build(opt_cls):
+        torch.manual_seed(0)
+        a = Conv2d(8, 8, 3, 1, 1, bias=True).to(gpu)
+        b = Conv2d(8, 8, 3, 1, 1, bias=True).to(gpu)
+        c = Conv2d(8, 8, 1, 1, 0, bias=True).to(gpu)
+        lin = torch.nn.Linear(8, 4).to(gpu)                         # torch-native: AccumulateGrad writes its gradient
+        for i, m in enumerate((a, b, c, lin)):
+            fill_module_(m, 70 + i)
+        ps = [p for m in (a, b, c, lin) for p in m.parameters()]
+        return (a, b, c, lin), opt_cls(ps, lr=0.05, momentum=0.9, weight_decay=1e-2, nesterov=True)
+
+    def run(mods, opt, schedule):
+        a, b, c, lin = mods
+        x = randn(75, 2, 8, 6, 6).to(gpu)
+        for use_b, use_c in schedule:
+            opt.zero_grad()
+            y = a(x)
+            if use_b:
+                y = y + b(x)
+            if use_c:
+                y = y + c(x)
+            out = lin(y.float().mean(dim=(2, 3)))
+            (out ** 2).sum().backward()
+            opt.step()
+        return [p.detach().float().cpu().clone() for m in mods for p in m.parameters()]
+
+    # reference semantics from torch itself, on plain torch modules with the same weights
+    def torch_ref(schedule):
+        mods = []
+        for i, (k, pad) in enumerate(((3, 1), (3, 1), (1, 0))):
+            m = torch.nn.Conv2d(8, 8, k, 1, pad).to(gpu)
+            fill_module_(m, 70 + i)
+            mods.append(m)
+        lin = torch.nn.Linear(8, 4).to(gpu)
+        fill_module_(lin, 73)
+        mods.append(lin)
+        opt = torch.optim.SGD([p for m in mods for p in m.parameters()], lr=0.05, momentum=0.9, weight_decay=1e-2, nesterov=True)
+        return run(mods, opt, schedule)
+
+    # b skips iteration 2 (after having momentum), c receives its first gradient only in iteration 3
+    schedule = [(True, False), (True, False), (False, False), (True, True), (True, True)]
+    mods, opt = build(FusedSGD)
+    got = run(mods, opt, schedule)
+    ref = torch_ref(schedule)
+    for i, (g, r) in enumerate(zip(got, ref)):
+        assert torch.allclose(g, r, rtol=2e-4, atol=2e-6), 'parameter %d: max diff %.3e' % (i, float((g - r).abs().max()))

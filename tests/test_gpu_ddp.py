@@ -69,3 +69,34 @@ def test_overlapped_gradient_exchange_equals_plain_exchange(gpu):
     assert off[0][1] == off[1][1]
     assert on[0][1] == off[0][1], 'overlapped and plain exchange disagree'
     assert on[0][2] > 10 and off[0][2] == 0          # the pieces really were launched from the hooks
+
+
+def test_train_cli_with_two_ranks(gpu, tmp_path):
+    """train1.py under torchrun with 2 ranks (gloo on the one test GPU): per-rank data shards, gradient exchange in the
+    pre-training and the A/B/C loop, summed validation counts, rank-0-only log / checkpoints, replicas bit-identical
+    after the epoch (the script checks parameter checksums over ranks and raises on drift); test.py on the result."""
+    import subprocess
+    import sys
+    from conftest import PKG
+    log = str(tmp_path / 'run')
+    env = dict(os.environ, PYTHONPATH=PKG, MI355_DIST_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    launch = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+              '--master-port', str(_free_port())]
+    common = ['data/none', '-t', 'Hand3DStudio', '--synthetic', '-a', 'resnet18', '-b', '4', '-i', '5', '-p', '2', '-j', '0',
+              '--image-size', '128', '--heatmap-size', '32', '--pretrain_epochs', '1', '--log', log]
+    r = subprocess.run(launch + [os.path.join(PKG, 'train1.py')] + common + ['--epochs', '1', '--pretrain', str(tmp_path / 'none.pth')],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    out = r.stdout
+    assert 'data parallel: 2 ranks' in out and 'replicas in sync' in out and 'Target(best)' in out
+    assert out.count('Start regression domain adaptation.') == 1          # rank 0 only
+    assert 'gradient exchange overlapped with the backward' in out
+    ck_path = os.path.join(log, 'checkpoints', '0.pth')
+    assert os.path.exists(ck_path) and os.path.exists(os.path.join(log, 'checkpoints', 'pretrain.pth'))
+    logs = [f for f in os.listdir(log) if f.endswith('.txt')]
+    assert len(logs) == 1, logs
+    # validation counts are summed over the two shards: 4*B = 16 samples per split
+    r = subprocess.run(launch[:-1] + [str(_free_port()), os.path.join(PKG, 'test.py')] + common + ['--checkpoint', ck_path],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert 'Source:' in r.stdout and 'fingertip:' in r.stdout

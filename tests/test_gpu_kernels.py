@@ -447,6 +447,14 @@ def test_device_label_generation_matches_generate_target(gpu):
     t, w = generate_target_device(torch.from_numpy(kp).to(gpu), torch.from_numpy(vis).to(gpu))
     assert np.array_equal(w.cpu().numpy(), ref_w)
     assert np.array_equal(t.cpu().numpy(), ref_t)
+    # and against the arrays the reference's own generate_target produced (golden G9), at three resolutions
+    from seeded import g9_inputs
+    g = golden('g9_generate_target')
+    kp, vis = g9_inputs()
+    for tag, (hm, img) in dict(a=(64, 256), b=(32, 128), c=(128, 512)).items():
+        t, w = generate_target_device(torch.from_numpy(kp * (img / 256.0)).to(gpu), torch.from_numpy(vis).to(gpu), hm, 2, img)
+        assert np.array_equal(w.cpu().numpy(), g['weight_' + tag]), tag
+        assert np.array_equal(t.cpu().numpy(), g['target_' + tag]), tag
 
 
 @pytest.mark.parametrize('dt', ['f32', 'bf16'])

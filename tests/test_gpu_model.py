@@ -342,3 +342,164 @@ def test_bf16_training_reduces_the_supervised_loss(gpu):
         assert last[0] < 0.66 * first, (first, last)
     finally:
         mi355.set_compute_dtype('f32')
+
+
+# ---------------------------------------------------------------- Bottleneck nets (the benchmarked architectures)
+def _g8_setup(gpu, arch='resnet50', seed=801):
+    import uda.model as models
+    from uda.model.pose_resnet2 import Upsampling
+    from uda.model.regda_7 import PoseResNetx9
+    bb = models.__dict__[arch](pretrained=False)
+    model = PoseResNetx9(bb, Upsampling(bb.out_features), 256, 21, num_head_layers=2, finetune=True)
+    fill_module_(model, seed)
+    return model.to(gpu)
+
+
+def _g8_batch(gpu):
+    B = 2
+    batch = dict(x_s=randn(802, B, 3, 256, 256), x_t=randn(8034, B, 3, 256, 256),
+                 label_s=rand(804, B, 21, 64, 64) * (rand(805, B, 21, 64, 64) > 0.9),
+                 w_s=weights_bk(806, B, 21), w_t=weights_bk(807, B, 21))
+    return {k: v.to(gpu) for k, v in batch.items()}
+
+
+@pytest.mark.parametrize('skip', [True, False])
+def test_g8_resnet50_iteration_matches_reference(gpu, skip):
+    """BASELINE config 2's network (ResNet-50: Bottleneck blocks, uda/model/resnet.py:92-107; 1x1 conv1 with the fused
+    residual-fork gradient, stride-2 3x3 beside a stride-2 1x1 downsample, 2048-channel BatchNorm): one complete A/B/C
+    iteration (train1.py:371-458, B=2, 256x256, fp32 mode) against values produced by the reference's own
+    PoseResNetx9 / loss classes (make_golden.py:g8_bottleneck): step-A forward 5-tuple, per-parameter gradient norms of
+    step A, the three losses, every parameter's |sum| after the iteration."""
+    from mi355.da_step import build_training
+    g = golden('g8_bottleneck')
+    model = _g8_setup(gpu)
+    batch = _g8_batch(gpu)
+    model.gl_layer.iter_num = 500
+    assert len(model.state_dict()) == 420
+    step, opts, scheds = build_training(model)
+    step.skip = skip
+    # step-A forward + backward alone first (gradients are consumed by the update inside run())
+    step._fwdbwd_A(batch)
+    torch.cuda.synchronize()
+    grads = {k: p.grad.detach().double().cpu() for k, p in model.named_parameters() if p.grad is not None}
+    assert sorted(grads) == list(g['gradA_keys'])
+    # Yardstick for everything that depends on gradients: the reference's own classes run in fp64 (golden keys *64).
+    # Gradients of this random-init network are ill-conditioned (reference fp32 vs fp64: up to 7e-3 on a norm), so the
+    # HIP fp32 path must be as close to fp64 as the reference's fp32 is (3x its distance + 1e-3).  Gradients that are
+    # exactly 0 in exact arithmetic (biases in front of a BatchNorm) hold rounding noise only and are skipped.
+    n32, n64 = g['gradA_norm'], g['gradA_norm64']
+    mine_rel, ref_rel = [], []
+    for k, a32, a64 in zip(g['gradA_keys'], n32, n64):
+        if a64 < 1e-6 * n64.max():
+            continue
+        n = float(grads[str(k)].norm())
+        mine_rel.append(abs(n - a64) / a64)
+        ref_rel.append(abs(a32 - a64) / a64)
+        assert abs(n - a64) <= 3 * abs(a32 - a64) + 3e-3 * a64, 'step-A gradient norm of %s: %.6e vs fp64 %.6e (ref fp32 %.6e)' % (k, n, a64, a32)
+    assert np.median(mine_rel) <= 3 * np.median(ref_rel) + 1e-4, (np.median(mine_rel), np.median(ref_rel))
+    assert max(mine_rel) <= 3 * max(ref_rel), (max(mine_rel), max(ref_rel))
+    model2 = _g8_setup(gpu)
+    model2.train()
+    y_s, y_s_adv, y_s_adv2, y_s_adv3, f_s = model2(batch['x_s'])
+    for name, t in dict(y_s=y_s, y_s_adv=y_s_adv, y_s_adv2=y_s_adv2, y_s_adv3=y_s_adv3).items():
+        _close(t[:, ::5], g[name], name=name)
+    _close(f_s[:, :8, :16, :16], g['f_slice'], name='f')
+    assert abs(float(f_s.detach().double().abs().sum()) - float(g['f_abs'])) <= 1e-3 * float(g['f_abs'])
+    # that forward updated the BN running statistics once: start again from the seeded state
+    fill_module_(model2, 801)
+    model2.gl_layer.iter_num = 500
+    step, opts, scheds = build_training(model2)
+    step.skip = skip
+    out = step.run(batch)
+    for s in scheds.values():
+        s.step()
+    got = np.array([float(out['loss_s']), float(out['loss_gf']), float(out['loss_gt'])])
+    assert abs(got[0] - g['losses'][0]) <= 1e-3 * g['losses'][0]          # step A: identical weights
+    for i in (1, 2):      # steps B, C run on updated weights: fp64 yardstick (reference fp32 vs fp64: 1.1e-3 / 5.8e-4)
+        l32, l64 = g['losses'][i], g['losses64'][i]
+        assert abs(got[i] - l64) <= 3 * abs(l32 - l64) + 1e-3 * abs(l64), (i, got[i], l32, l64)
+    sd = model2.state_dict()
+    keys = sorted(k for k in sd if not k.endswith('num_batches_tracked'))
+    assert keys == list(g['param_keys'])
+    a = np.array([float(sd[k].double().abs().sum()) for k in keys])
+    rel = np.abs(a - g['param_abs']) / (np.abs(g['param_abs']) + 1e-12)
+    assert rel.max() <= 1e-3, 'param |sum| mismatch: %s rel %.3e' % (keys[int(rel.argmax())], rel.max())
+    assert int(sd['backbone.layer4.2.bn3.num_batches_tracked']) == int(g['nbt_layer4']) == 3
+    assert model2.backbone.fc.weight.grad is None
+
+
+def test_g8_resnet101_forward_matches_reference(gpu):
+    """BASELINE config 3's network (ResNet-101, 23 Bottleneck blocks in layer3): train-mode forward, BN running
+    statistics of the deepest stages (fp64 yardstick, see make_golden.py:g8_bottleneck), eval-mode forward 1e-3, bf16 eval
+    heat-maps 6e-2 (through 100+ layers)."""
+    import mi355
+    g = golden('g8_bottleneck')
+    m = _g8_setup(gpu, 'resnet101', 811)
+    assert len(m.state_dict()) == 726
+    x = randn(812, 2, 3, 256, 256).to(gpu)
+    m.train()
+    with torch.no_grad():
+        y, y_adv, y_adv2, y_adv3, f = m(x)
+    def close64(t, key):
+        """as close to the reference run in fp64 as the reference's own fp32 run is (3x its distance + 1e-3 of the scale)"""
+        r32, r64 = np.asarray(g[key], np.float64), np.asarray(g[key + '64'])
+        scale = float(np.abs(r64).max())
+        gap = float(np.abs(r32 - r64).max())
+        err = float(np.abs(t.detach().double().cpu().numpy() - r64).max())
+        assert err <= 3 * gap + 1e-3 * scale, '%s: %.3e from fp64 (reference fp32: %.3e, scale %.3e)' % (key, err, gap, scale)
+    close64(y[:, ::5], 'r101_y')
+    close64(y_adv3[:, ::5], 'r101_y_adv3')
+    close64(f[:, :8, :16, :16], 'r101_f_slice')
+    assert abs(float(f.double().abs().sum()) - float(g['r101_f_abs64'])) <= 1e-3 * float(g['r101_f_abs64'])
+    sd = m.state_dict()
+    close64(sd['backbone.layer3.22.bn3.running_mean'], 'r101_rm')
+    close64(sd['backbone.layer4.2.bn3.running_var'], 'r101_rv')
+    m.eval()
+    with torch.no_grad():
+        _close(m(x)[:, ::5], g['r101_y_eval'], name='y_eval')
+        mi355.set_compute_dtype('bf16')
+        _close(m(x)[:, ::5], g['r101_y_eval'], tol=6e-2, name='y_eval_bf16')
+
+
+def test_full_size_resnet50_bf16_iteration_properties(gpu):
+    """BASELINE config 2 at full size (ResNet-50, 256x256, B=64 source + 64 target, bf16): no oracle finishes this in
+    seconds, so size-independent properties: finite losses, the shared B/C part of the network updates its running
+    statistics twice (num_batches_tracked: A once + B/C twice = 3 per iteration; adversarial heads: 3 forwards),
+    backbone.fc never receives a gradient, every stepped parameter moved and stays finite over two iterations."""
+    import mi355
+    import uda.model as models
+    from mi355.da_step import build_training
+    from uda.model.pose_resnet2 import Upsampling
+    from uda.model.regda_7 import PoseResNetx9
+    from utils.synthetic import make_batch
+    mi355.set_compute_dtype('bf16')
+    try:
+        torch.manual_seed(1)
+        bb = models.resnet50(pretrained=False)
+        model = PoseResNetx9(bb, Upsampling(bb.out_features), 256, 21, num_head_layers=2, finetune=True).to(gpu)
+        before = {k: v.detach().clone() for k, v in model.named_parameters()}
+        step, opts, scheds = build_training(model)
+        batch = make_batch(64, 256, 64, seed=1, device=gpu)
+        out = step.run(batch)
+        for s in scheds.values():
+            s.step()
+        torch.cuda.synchronize()
+        vals = [float(out[k]) for k in ('loss_s', 'loss_gf', 'loss_gt')]
+        assert all(np.isfinite(v) for v in vals), vals
+        sd = model.state_dict()
+        assert int(sd['backbone.layer4.2.bn3.num_batches_tracked']) == 3
+        assert int(sd['upsampling.7.num_batches_tracked']) == 3
+        assert int(sd['head.1.num_batches_tracked']) == 3
+        assert int(sd['head_adv3.last_lay.6.num_batches_tracked']) == 3
+        assert model.backbone.fc.weight.grad is None and model.backbone.fc.bias.grad is None
+        for k, p in model.named_parameters():
+            if k.startswith('backbone.fc.'):
+                assert torch.equal(p, before[k]), k
+            else:
+                assert torch.isfinite(p).all(), k
+                assert not torch.equal(p, before[k]), 'parameter %s was not updated' % k
+        out2 = step.run(batch)
+        torch.cuda.synchronize()
+        assert all(np.isfinite(float(out2[k])) for k in ('loss_s', 'loss_gf', 'loss_gt'))
+    finally:
+        mi355.set_compute_dtype('f32')

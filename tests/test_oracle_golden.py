@@ -150,6 +150,40 @@ def test_g7_full_iteration():
     np.testing.assert_allclose(s, g['param_sum'], rtol=1e-4, atol=1e-4)
 
 
+def test_g8_bottleneck_iteration_and_resnet101_forward():
+    """Bottleneck nets (ResNet-50 full A/B/C iteration, ResNet-101 forward) against the values captured from the
+    reference's PoseResNetx9 / loss classes (make_golden.py:g8_bottleneck)."""
+    g = golden('g8_bottleneck')
+    bb = make_backbone('resnet50')
+    model = op.PoseResNetx9(bb, op.Upsampling(bb.out_features), 256, 21)
+    fill_module_(model, 801)
+    B = 2
+    x_s, x_t = randn(802, B, 3, 256, 256), randn(8034, B, 3, 256, 256)
+    label_s = rand(804, B, 21, 64, 64) * (rand(805, B, 21, 64, 64) > 0.9)
+    w_s, w_t = weights_bk(806, B, 21), weights_bk(807, B, 21)
+    model.gl_layer.iter_num = 500
+    out = DATrainer(model).step(x_s, label_s, w_s, x_t, w_t)
+    got = np.array([float(out['loss_s']), float(out['loss_gf']), float(out['loss_gt'])])
+    np.testing.assert_allclose(got, g['losses'], rtol=2e-5)
+    np.testing.assert_allclose(out['y_s'][:, ::5].numpy(), g['y_s'], rtol=1e-4, atol=1e-5)
+    sd = model.state_dict()
+    keys = sorted(k for k in sd if not k.endswith('num_batches_tracked'))
+    assert keys == list(g['param_keys'])
+    a = np.array([float(sd[k].double().abs().sum()) for k in keys])
+    np.testing.assert_allclose(a, g['param_abs'], rtol=1e-5)
+    assert int(sd['backbone.layer4.2.bn3.num_batches_tracked']) == int(g['nbt_layer4']) == 3
+    bb = make_backbone('resnet101')
+    m = op.PoseResNetx9(bb, op.Upsampling(bb.out_features), 256, 21)
+    fill_module_(m, 811)
+    m.train()
+    x = randn(812, B, 3, 256, 256)
+    with torch.no_grad():
+        y, _, _, y_adv3, f = m(x)
+    np.testing.assert_allclose(y[:, ::5].numpy(), g['r101_y'], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(y_adv3[:, ::5].numpy(), g['r101_y_adv3'], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(m.state_dict()['backbone.layer3.22.bn3.running_mean'].numpy(), g['r101_rm'], rtol=1e-4, atol=1e-6)
+
+
 def test_synthetic_labels_follow_generate_target():
     """The package's label generator (used for synthetic batches) against the oracle's restatement of
     uda/dataset/util.py:9-68, including centres on / outside the border."""
@@ -161,3 +195,21 @@ def test_synthetic_labels_follow_generate_target():
     a, wa = ol.generate_target(joints, vis, (64, 64), 2, (256, 256))
     b, wb = gt_pkg(joints, vis, (64, 64), 2, (256, 256))
     assert np.array_equal(a, b) and np.array_equal(wa, wb)
+
+
+def test_g9_generate_target_matches_reference():
+    """uda/dataset/util.py:9-68 captured from the reference itself (make_golden.py:g9_generate_target): the oracle's
+    restatement and the package's host-side generator, bit-exact, at 256/128/512 images (64/32/128 heat-maps), with
+    centres on and across every border, far outside the map, and invisible joints."""
+    from seeded import g9_inputs
+    from utils.synthetic import generate_target as gt_pkg
+    g = golden('g9_generate_target')
+    kp, vis = g9_inputs()
+    for tag, (hm, img) in dict(a=((64, 64), (256, 256)), b=((32, 32), (128, 128)), c=((128, 128), (512, 512))).items():
+        for fn in (ol.generate_target, gt_pkg):
+            for b in range(kp.shape[0]):
+                t, w = fn(kp[b] * (img[0] / 256.0), vis[b], hm, 2, img)
+                assert np.array_equal(t, g['target_' + tag][b]) and np.array_equal(w, g['weight_' + tag][b]), (tag, b, fn.__module__)
+    # int() truncates toward zero: x = -2.1 px -> -0.025 -> column 0 (kept); far outside -> weight 0
+    assert g['weight_a'][0, 5, 0] == 1 and g['weight_a'][0, 4, 0] == 1 and g['weight_a'][1, 6, 0] == 0 and g['weight_a'][1, 7, 0] == 0
+
