@@ -8,7 +8,9 @@ out-of-scope CPU dataset layer), ``--dtype {bf16,f32}``, ``--no-graph``.
 
 Data parallel (the reference is single-process): start one process per GPU with torchrun,
 
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 train1.py data/H3D ... -b 64
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 train1.py -- data/H3D ... -b 64
+
+(the ``--`` keeps torchrun's own parser away from the script's flags: ``--log`` is an ambiguous prefix of its ``--log-dir``).
 
 ``-b`` stays the per-GPU batch (the path shards by image, BatchNorm statistics stay per GPU as in the reference).  Every
 rank reads ``RANK / LOCAL_RANK / WORLD_SIZE`` before touching the GPU, draws its own shard of both training sets

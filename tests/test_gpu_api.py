@@ -164,7 +164,7 @@ def test_gradient_layer_scales_whatever_consumes_it(gpu, dt):
     tdt = mi355.compute_dtype()
     tol = 1e-5 if dt == 'f32' else 2e-2
     conv = Conv2d(16, 16, 3, 1, 1, bias=False).to(gpu)
-    conv2 = Conv2d(16, 24, 1, 1, 0, bias=True).to(gpu)
+    conv2 = Conv2d(16, 32, 1, 1, 0, bias=True).to(gpu)
     fill_module_(conv, 41); fill_module_(conv2, 42)
     gl = WarmStartGradientLayer(alpha=1.0, lo=0.0, hi=0.1, max_iters=1000, auto_step=False)
     gl.iter_num = 700

@@ -84,7 +84,7 @@ def test_train_cli_with_two_ranks(gpu, tmp_path):
               '--master-port', str(_free_port())]
     common = ['data/none', '-t', 'Hand3DStudio', '--synthetic', '-a', 'resnet18', '-b', '4', '-i', '5', '-p', '2', '-j', '0',
               '--image-size', '128', '--heatmap-size', '32', '--pretrain_epochs', '1', '--log', log]
-    r = subprocess.run(launch + [os.path.join(PKG, 'train1.py')] + common + ['--epochs', '1', '--pretrain', str(tmp_path / 'none.pth')],
+    r = subprocess.run(launch + [os.path.join(PKG, 'train1.py'), '--'] + common + ['--epochs', '1', '--pretrain', str(tmp_path / 'none.pth')],
                        env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     out = r.stdout
@@ -96,7 +96,7 @@ def test_train_cli_with_two_ranks(gpu, tmp_path):
     logs = [f for f in os.listdir(log) if f.endswith('.txt')]
     assert len(logs) == 1, logs
     # validation counts are summed over the two shards: 4*B = 16 samples per split
-    r = subprocess.run(launch[:-1] + [str(_free_port()), os.path.join(PKG, 'test.py')] + common + ['--checkpoint', ck_path],
+    r = subprocess.run(launch[:-1] + [str(_free_port()), os.path.join(PKG, 'test.py'), '--'] + common + ['--checkpoint', ck_path],
                        env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert 'Source:' in r.stdout and 'fingertip:' in r.stdout

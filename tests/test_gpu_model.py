@@ -278,15 +278,30 @@ def _supervised_grads(gpu, dtype_name, bnbwd=False):
 
 
 def test_bf16_gradients_track_the_fp32_path(gpu):
-    """The throughput mode (bf16 storage / MFMA bf16, fp32 accumulate) runs kernels the fp32 parity mode never touches
-    (the kw-shared 3x3 wgrad kernel, bf16 tr16 LDS reads).  This random-init fixture amplifies rounding by ~2.5e5 from
-    head to stem (fp32 vs fp64 oracle: 1.5e-2), so bf16 (eps 4e-3) can only be held tightly near the loss: main-head
-    parameters within 0.2 relative L2 (observed 0.02 - 0.13); deeper down the error grows smoothly with depth (0.14 at
-    the last neck layer ... 0.57 at the stem, cosine 0.83) and the test asks for direction agreement: cosine >= 0.6
-    everywhere.  A wrong tap, sign or missing term in any bf16 kernel breaks that by a wide margin."""
+    """Whole-network gradients of the throughput mode (bf16 storage / MFMA bf16, fp32 accumulate).  This random-init fixture
+    amplifies rounding by ~2.5e5 from head to stem (fp32 vs fp64 oracle: 1.5e-2), so no bf16 implementation can be close
+    to fp32 deep in the network; the yardstick is torch's own bfloat16 CPU run of the oracle model on the same fixture:
+    for every parameter the HIP bf16 path must be as close to the fp64 oracle as that run is (2x its distance + 3e-2;
+    observed: ours 0.02 .. 0.57, torch CPU bf16 0.02 .. 0.6), main-head parameters within 0.2, and every gradient must
+    agree in direction with the fp32 path (cosine >= 0.6).  Layer-exact bf16 evidence: tests/test_gpu_bf16_layers.py."""
+    from oracle.backbone import make_backbone
+    from oracle import pose as op
+    from oracle import losses as ol
     g32 = _supervised_grads(gpu, 'f32')
     g16 = _supervised_grads(gpu, 'bf16')
     assert set(g32) == set(g16)
+    _, _, _, _, batch = _g7_setup(gpu)
+    G = {}
+    for dt in (torch.float64, torch.bfloat16):
+        bb = make_backbone('resnet18')
+        ref = op.PoseResNetx9(bb, op.Upsampling(bb.out_features), 256, 21)
+        fill_module_(ref, 701)
+        ref = ref.to(dt).train()
+        y = ref(batch['x_s'].cpu().to(dt))[0]
+        acc = torch.float64 if dt == torch.float64 else torch.float32
+        ol.JointsKLLoss()(y.to(acc), batch['label_s'].cpu().to(acc), batch['w_s'].cpu().to(acc)).backward()
+        G[dt] = {k: p.grad.double() for k, p in ref.named_parameters() if p.grad is not None}
+    assert set(G[torch.float64]) == set(g16)
     for k, t in g32.items():
         if float(t.abs().max()) < 1e-6:
             continue
@@ -296,6 +311,11 @@ def test_bf16_gradients_track_the_fp32_path(gpu):
         assert cos >= 0.6, '%s: cosine %.3f' % (k, cos)
         if k.startswith('head.'):
             assert e <= 0.2, '%s: bf16 vs fp32 relative L2 %.3e' % (k, e)
+        t64 = G[torch.float64][k]
+        n64 = float(t64.norm())
+        e_mine = float((g16[k] - t64).norm()) / n64
+        e_torch = float((G[torch.bfloat16][k] - t64).norm()) / n64
+        assert e_mine <= 2 * e_torch + 3e-2, '%s: HIP bf16 %.3e from fp64, torch CPU bf16 %.3e' % (k, e_mine, e_torch)
 
 
 def test_optin_bn_backward_fusion_matches_default(gpu):
