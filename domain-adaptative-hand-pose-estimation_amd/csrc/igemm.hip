@@ -1239,8 +1239,11 @@ static int check_desc(const mi355_conv_desc* d) {
   if (d->stride < 1 || d->stride > 2) MI_FAIL(MI355_EINVAL, "unsupported stride %d", d->stride);
   if (d->Ho != (d->Hi + 2 * d->pad - d->kh) / d->stride + 1 || d->Wo != (d->Wi + 2 * d->pad - d->kw) / d->stride + 1)
     MI_FAIL(MI355_EINVAL, "conv desc: output size %dx%d inconsistent with input %dx%d k%d s%d p%d", d->Ho, d->Wo, d->Hi, d->Wi, d->kh, d->stride, d->pad);
-  if ((long)d->N * d->Hi * d->Wi * d->Ci >= (1L << 31) || (long)d->N * d->Ho * d->Wo * d->Co >= (1L << 31))
-    MI_FAIL(MI355_EINVAL, "tensor too large for 32-bit element offsets");
+  // the kernels form signed 32-bit BYTE offsets and 32-bit buffer-resource sizes: bound bytes, not elements
+  const long esz = d->dtype == MI355_BF16 ? 2 : 4;
+  if ((long)d->N * d->Hi * d->Wi * d->Ci * esz >= (1L << 31) || (long)d->N * d->Ho * d->Wo * d->Co * esz >= (1L << 31))
+    MI_FAIL(MI355_EINVAL, "tensor too large for 32-bit byte offsets (%ld / %ld bytes): split the batch",
+            (long)d->N * d->Hi * d->Wi * d->Ci * esz, (long)d->N * d->Ho * d->Wo * d->Co * esz);
   return MI355_OK;
 }
 

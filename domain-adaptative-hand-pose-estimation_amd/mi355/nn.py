@@ -166,6 +166,18 @@ def _claim_gl(x, dtype):
     return x, None
 
 
+class GradFanIn:
+    """Gradient fan-in of a tensor that several mi355 convs consume (the neck output f feeds four heads,
+    uda/model/regda_7.py:4931-4946).  Autograd would add the consumers' input gradients with one element-wise kernel per
+    extra consumer; instead the first consumer's dgrad writes the buffer and every later one accumulates onto it inside
+    its own epilogue (mi355_conv_dgrad accumulate=1) and hands autograd nothing (None = zero): same sum, same bf16
+    rounding after each addition, no extra pass over the tensor.  Attach one to the tensor: ``f._mi_fan = GradFanIn()``."""
+    __slots__ = ('buf',)
+
+    def __init__(self):
+        self.buf = None
+
+
 def _take_partial(mod, y):
     """Move the statistics partials a conv's forward left on its module onto the output tensor (read by BatchNorm2d)."""
     part = mod._last_partial
@@ -177,8 +189,9 @@ def _take_partial(mod, y):
 
 class _ConvFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, residual, mod, scale_dev):
+    def forward(ctx, x, weight, bias, residual, mod, scale_dev, fan=None):
         desc, wf, _ = mod._plan(x)
+        ctx.fan = fan
         if mod._want_stats() and residual is None:
             y, mod._last_partial = ops.conv_fwd_stats(desc, x, wf, bias)
         else:
@@ -199,12 +212,18 @@ class _ConvFn(torch.autograd.Function):
             mod._wgrad(desc, x, dy, weight)          # off the critical path: side stream
         if ctx.needs_input_grad[0]:
             _, _, wt = mod._plan(x)
-            dx = _dgrad_for_bn(desc, dy, wt, ctx.bn_src, x, scale_dev=ctx.scale_dev)
+            fan = ctx.fan
+            if fan is not None and fan.buf is not None and fan.buf.shape == x.shape and fan.buf.dtype == x.dtype:
+                _dgrad_for_bn(desc, dy, wt, ctx.bn_src, x, scale_dev=ctx.scale_dev, out=fan.buf, accumulate=True)
+            else:
+                dx = _dgrad_for_bn(desc, dy, wt, ctx.bn_src, x, scale_dev=ctx.scale_dev)
+                if fan is not None:
+                    fan.buf = dx
         if ctx.has_bias and ctx.needs_input_grad[2]:
             g, acc = grad_slot(bias)
             ops.colsum(dy, g, acc)
         dres = dy if ctx.needs_input_grad[3] else None
-        return dx, None, None, dres, None, None
+        return dx, None, None, dres, None, None, None
 
 
 class _ConvSkipFn(torch.autograd.Function):
@@ -546,7 +565,8 @@ class Conv2d(nn.Module):
         else:
             x = _as_feature(x, dtype)
         self._in_bn_src = _bn_src_of(x)
-        return _take_partial(self, _ConvFn.apply(x, self.weight, self.bias, residual, self, scale))
+        fan = getattr(x, '_mi_fan', None) if torch.is_grad_enabled() and x.requires_grad else None
+        return _take_partial(self, _ConvFn.apply(x, self.weight, self.bias, residual, self, scale, fan))
 
     def forward_skip(self, x):
         """(conv(x), alias of x): for residual blocks, see _ConvSkipFn.  Bias-free MFMA convs only."""

@@ -8,7 +8,7 @@ from typing import Optional
 import torch
 import torch.nn as nn
 
-from mi355.nn import Conv2d, BatchNorm2d, ReLU, FusedSequential
+from mi355.nn import Conv2d, BatchNorm2d, ReLU, FusedSequential, GradFanIn
 from utils.gl import WarmStartGradientLayer
 from uda.model.regda_4 import _GaussianLabels, PseudoLabelGenerator
 
@@ -101,6 +101,7 @@ class PoseResNetx9(nn.Module):
                 return self.upsampling(self.backbone(x))
         f = self.upsampling(self.backbone(x))
         f._mi_bn_src = None      # f feeds four heads: its gradient is a sum, no single dgrad epilogue can reduce it
+        f._mi_fan = GradFanIn()  # ... and that sum is formed inside the heads' dgrad epilogues, not by autograd add kernels
         return f
 
     def adv_heads(self, f):

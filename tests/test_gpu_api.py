@@ -249,3 +249,41 @@ def test_fused_sgd_is_a_drop_in_for_torch_sgd(gpu):
     ref = torch_ref(schedule)
     for i, (g, r) in enumerate(zip(got, ref)):
         assert torch.allclose(g, r, rtol=2e-4, atol=2e-6), 'parameter %d: max diff %.3e' % (i, float((g - r).abs().max()))
+
+
+@pytest.mark.parametrize('dt', ['f32', 'bf16'])
+def test_gradient_fan_in_is_summed_inside_the_dgrad_epilogues(gpu, dt):
+    """A tensor consumed by several mi355 convs (the neck output feeds four heads): with a GradFanIn attached the
+    consumers accumulate their input gradients into one buffer; the result equals autograd's own sum."""
+    import mi355
+    from mi355.nn import Conv2d, GradFanIn
+    from utils.gl import WarmStartGradientLayer
+    mi355.set_compute_dtype(dt)
+    tdt = mi355.compute_dtype()
+    convs = [Conv2d(16, 16, 3, 1, 1, bias=True).to(gpu), Conv2d(16, 32, 1, 1, 0, bias=False).to(gpu), Conv2d(16, 16, 3, 2, 1, bias=True).to(gpu)]
+    for i, c in enumerate(convs):
+        fill_module_(c, 90 + i)
+    gl = WarmStartGradientLayer(alpha=1.0, lo=0.0, hi=0.1, max_iters=1000, auto_step=False)
+    gl.iter_num = 900
+    x0 = randn(95, 2, 16, 12, 12).to(gpu).to(tdt).contiguous(memory_format=torch.channels_last)
+
+    def run(fan):
+        x = x0.clone().requires_grad_(True)
+        h = x * 1.0                                     # a non-leaf, like the neck output
+        h = h.contiguous(memory_format=torch.channels_last)
+        if fan:
+            h._mi_fan = GradFanIn()
+        ha = gl(h)                                      # two of the three consumers sit behind the gradient layer
+        loss = convs[0](h).float().sum() + 2.0 * convs[1](ha).float().sum() + 3.0 * convs[2](ha).float().pow(2).sum()
+        for c in convs:
+            for p in c.parameters():
+                p.grad = None
+        loss.backward()
+        return x.grad.float(), [p.grad.clone() for c in convs for p in c.parameters()]
+
+    g_ref, w_ref = run(False)
+    g_fan, w_fan = run(True)
+    scale = float(g_ref.abs().max())
+    assert float((g_fan - g_ref).abs().max()) <= (1e-5 if dt == 'f32' else 2e-2) * scale
+    for a, b in zip(w_fan, w_ref):
+        assert torch.equal(a, b)
