@@ -30,7 +30,9 @@ for p in (ROOT, PKG):
 # forward conv+deconv GFLOPs per image (2*MAC), SURVEY.md table A3 / BASELINE.md section 4
 F_GFLOP = {('resnet18', 128): 5.611, ('resnet18', 256): 22.443, ('resnet50', 256): 29.188,
            ('resnet101', 256): 38.885, ('resnet101', 512): 155.540}
-PEAK_TFLOPS = {'bf16': 2500.0, 'f32': 157.3}     # dense MFMA peaks, MI355X_MICROARCH.md
+# dense MFMA peaks, MI355X_MICROARCH.md.  'fp8' mode uses the NON-scaled v_mfma_f32_32x32x16_fp8_fp8, which issues at the bf16
+# rate (the ~5 PFLOP/s fp8 figure belongs to the block-scaled K=64 instruction): its roofline is the bf16 one.
+PEAK_TFLOPS = {'bf16': 2500.0, 'f32': 157.3, 'fp8': 2500.0}
 
 
 def parse():
@@ -41,7 +43,8 @@ def parse():
     ap.add_argument('--arch', default='resnet50')
     ap.add_argument('--batch-size', type=int, default=64, help='per-GPU batch (source) = per-GPU batch (target)')
     ap.add_argument('--image-size', type=int, default=256)
-    ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f32'])
+    ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f32', 'fp8'],
+                    help="'fp8': bf16 storage, fp8 (e4m3 / e5m2) operands in the forward / input-gradient GEMMs of the K-heavy convs")
     ap.add_argument('--no-graph', action='store_true', help='launch eagerly instead of replaying HIP graphs')
     ap.add_argument('--graph', action='store_true', help='replay HIP graphs also with more than one rank (default there: eager; '
                     'at B=64 the iteration is GPU-bound either way: 44.72 ms replayed vs 44.75 ms eager)')
@@ -242,13 +245,13 @@ def main():
         ms, launches, flops, abytes = ops.prof_read()
         log('roofline pass done')
         # executed -> algorithmic FLOPs: the 3-channel stem runs padded to one 16-byte chunk (8 bf16 / 4 fp32 channels)
-        cpad = 8 if args.dtype == 'bf16' else 4
+        cpad = 4 if args.dtype == 'f32' else 8
         stem_m = B * (S // 2) * (S // 2)
         stem_excess = 2.0 * stem_m * 64 * 49 * (cpad - 3) * 4 * n_prof     # 2 fwd (A, shared B+C) + 2 wgrad (A, C) launches / iteration
         algo = flops - stem_excess
         ach = algo / (ms * 1e-3) / 1e12
         peak = PEAK_TFLOPS[args.dtype]
-        roof = {'bound': 'mfma', 'kernel': 'gather_gemm_kernel + wgrad_gemm_kernel + wgrad_kw_kernel (implicit-GEMM conv family)',
+        roof = {'bound': 'mfma', 'kernel': 'gather_gemm_kernel%s + wgrad_gemm_kernel + wgrad_kw_kernel (implicit-GEMM conv family)' % (' + gather_fp8_kernel' if args.dtype == 'fp8' else ''),
                 'achieved': round(ach, 2), 'peak': peak, 'unit': 'TFLOP/s', 'frac': round(ach / peak, 4),
                 'traffic': pmc_traffic(args), 'traffic_unit': 'bytes per launch (rocprofv3 PMC: 2*FETCH_SIZE + WRITE_SIZE, separate passes)',
                 'algorithmic_bytes_per_launch': round(abytes / launches), 'launches_per_step': launches // n_prof,

@@ -10,7 +10,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 OUT = os.path.join(HERE, 'libmi355pose.so')
-SOURCES = ['api.hip', 'igemm.hip', 'bn.hip', 'pool_layout.hip', 'pw21.hip', 'heatmap.hip', 'optim.hip']
+SOURCES = ['api.hip', 'igemm.hip', 'igemm_fp8.hip', 'bn.hip', 'pool_layout.hip', 'pw21.hip', 'heatmap.hip', 'optim.hip']
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-function',
          '-ffp-contract=off']   # no implicit FMA contraction: keep fp32 parity with the ATen op order
@@ -26,7 +26,7 @@ def _newer(src_list, target):
 def build(force=False, verbose=True):
     bdir = os.path.join(CSRC, '_build')
     os.makedirs(bdir, exist_ok=True)
-    hdrs = [os.path.join(CSRC, 'common.h'), os.path.join(HERE, '..', 'include', 'mi355pose.h')]
+    hdrs = [os.path.join(CSRC, 'common.h'), os.path.join(CSRC, 'igemm_common.h'), os.path.join(HERE, '..', 'include', 'mi355pose.h')]
     jobs = []
     for s in SOURCES:
         src = os.path.join(CSRC, s)

@@ -8,61 +8,7 @@
 #include "common.h"
 #include <stdlib.h>
 
-#define MAX_TAPS 52
-struct Tap { int8_t dy, dx; int16_t widx; };
-
-// One launch covers up to 4 independent sub-problems ("phases") that share A, B, D and the tile shape: the stride^2
-// output phases of a strided dgrad / ConvTranspose forward, each a unit-stride gather over its own tap subset.
-// Logical tile id = tile_in_phase * nphase + phase, so every XCD gets the same mix of light and heavy phases.
-struct Phase { int OHp, OWp, out_oy, out_ox, M, ntaps, tap0, ntm; };
-struct GatherArgs {
-  const void* A; const void* B; void* D;
-  const float* bias; const void* residual; const float* scale;
-  int Hi, Wi, Ci;
-  int in_sy, in_sx;
-  int Ho, Wo;
-  int out_sy, out_sx;
-  int Nout, ldb, ldd;
-  int cshift;
-  int accumulate;
-  int nphase, ntn, ntiles;     // ntiles = nphase * max_phase(ntm) * ntn
-  int hw;                      // heat-map output mode: pixels per image
-  int lw;                      // KW3: log2(min(W, 128))
-  unsigned a_bytes, b_bytes;
-  size_t stat_bytes;           // (host) capacity of stat_partial
-  int stat_slices;             // (host) slices the launch writes: nphase * ntm, 0 when the statistics were not fused
-  // BatchNorm BACKWARD reduction fused into the epilogue: this launch produces dy of a BatchNorm whose input was bnb_x
-  // (same shape as D); per m-tile slice and channel it leaves (sum dy_eff, sum dy_eff * xhat) in bnb_partial[slice][Nout][2].
-  // bnb_relu: 0 none, 1 mask from bnb_y > 0, 2 mask recomputed from bnb_x (see bn.hip).
-  const void* bnb_x; const void* bnb_y;
-  const float* bnb_mean; const float* bnb_invstd; const float* bnb_gamma; const float* bnb_beta;
-  float* bnb_partial; int bnb_relu;
-  float* stat_partial;         // BatchNorm statistics of the OUTPUT fused into the epilogue: [m-tile slice][Nout][n, mean, M2]
-  Phase ph[4];
-  Tap taps[MAX_TAPS];
-};
-
-// swizzled byte offset of 16-byte chunk `c` (0..7) in 128-byte row `r`
-__device__ __forceinline__ int swz128(int r, int c) { return r * 128 + ((c ^ ((r >> 1) & 7)) << 4); }
-
-// XCD-aware bijective remap of the linear block id (blocks b and b+8 share an XCD / L2).
-__device__ __forceinline__ int xcd_remap(int bid, int nblk) {
-  int q = nblk >> 3, r = nblk & 7, x = bid & 7, i = bid >> 3;
-  int start = (x < r) ? x * (q + 1) : r * (q + 1) + (x - r) * q;
-  return start + i;
-}
-
-// 16-byte load through a buffer descriptor: out-of-range offsets (>= num_records) return zeros, so halo / tail
-// handling needs no branch and no zero-initialised destination.
-typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
-#define OOB_OFF ((int)0x80000000)
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsigned bytes) {
-  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
-}
-__device__ __forceinline__ uint4 buf_load16(__amdgpu_buffer_rsrc_t rs, int byte_off) {
-  u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(rs, byte_off, 0, 0);
-  return make_uint4(v[0], v[1], v[2], v[3]);
-}
+#include "igemm_common.h"
 
 template <typename T> struct MmaTraits;
 template <> struct MmaTraits<bf16_t> { static constexpr int BK = 64; static constexpr int CH = 8; };
@@ -1234,13 +1180,13 @@ static int dispatch_gather(GatherArgs& a, hipStream_t st) {
 
 static int check_desc(const mi355_conv_desc* d) {
   if (!d) MI_FAIL(MI355_EINVAL, "null conv desc");
-  if (d->dtype != MI355_F32 && d->dtype != MI355_BF16) MI_FAIL(MI355_EINVAL, "bad dtype %d", d->dtype);
+  if (d->dtype != MI355_F32 && d->dtype != MI355_BF16 && d->dtype != MI355_FP8) MI_FAIL(MI355_EINVAL, "bad dtype %d", d->dtype);
   if (d->kh * d->kw > MAX_TAPS || d->kh < 1 || d->kw < 1) MI_FAIL(MI355_EINVAL, "unsupported kernel %dx%d", d->kh, d->kw);
   if (d->stride < 1 || d->stride > 2) MI_FAIL(MI355_EINVAL, "unsupported stride %d", d->stride);
   if (d->Ho != (d->Hi + 2 * d->pad - d->kh) / d->stride + 1 || d->Wo != (d->Wi + 2 * d->pad - d->kw) / d->stride + 1)
     MI_FAIL(MI355_EINVAL, "conv desc: output size %dx%d inconsistent with input %dx%d k%d s%d p%d", d->Ho, d->Wo, d->Hi, d->Wi, d->kh, d->stride, d->pad);
   // the kernels form signed 32-bit BYTE offsets and 32-bit buffer-resource sizes: bound bytes, not elements
-  const long esz = d->dtype == MI355_BF16 ? 2 : 4;
+  const long esz = d->dtype == MI355_F32 ? 4 : 2;      // (fp8 operands, bf16 results: bound by the wider side)
   if ((long)d->N * d->Hi * d->Wi * d->Ci * esz >= (1L << 31) || (long)d->N * d->Ho * d->Wo * d->Co * esz >= (1L << 31))
     MI_FAIL(MI355_EINVAL, "tensor too large for 32-bit byte offsets (%ld / %ld bytes): split the batch",
             (long)d->N * d->Hi * d->Wi * d->Ci * esz, (long)d->N * d->Ho * d->Wo * d->Co * esz);
@@ -1259,9 +1205,13 @@ static int check_bnb(const mi355_bn_bwd_src* bn, const float* partial, const int
   if (bn->relu && !bn->y && (!bn->gamma || !bn->beta)) MI_FAIL(MI355_EINVAL, "bnbwd fusion: relu without y needs gamma and beta");
   return MI355_OK;
 }
+// fp8 operand launches: device scalars undoing the operand scales, and the format of the gathered operand
+struct Fp8Extra { const float* descale_a; const float* descale_b; int a_fmt; };
 static int conv_fwd_impl(const mi355_conv_desc* d, const void* x, const void* w, const float* bias, const void* residual, void* y,
-                         float* partial, size_t partial_bytes, int* nslices, void* stream, const mi355_bn_bwd_src* bn = nullptr) {
+                         float* partial, size_t partial_bytes, int* nslices, void* stream, const mi355_bn_bwd_src* bn = nullptr,
+                         const Fp8Extra* f8 = nullptr) {
   if (int e = check_desc(d)) return e;
+  if ((d->dtype == MI355_FP8) != (f8 != nullptr)) MI_FAIL(MI355_EINVAL, "fp8 descriptors go through the *_fp8 entry points (and only they)");
   GatherArgs a; memset(&a, 0, sizeof(a));
   a.A = x; a.B = w; a.D = y; a.bias = bias; a.residual = residual; a.scale = nullptr;
   a.Hi = d->Hi; a.Wi = d->Wi; a.Ci = d->Ci; a.in_sy = a.in_sx = d->stride;
@@ -1272,9 +1222,19 @@ static int conv_fwd_impl(const mi355_conv_desc* d, const void* x, const void* w,
   else { a.stat_partial = partial; a.stat_bytes = partial_bytes; }
   for (int i = 0; i < d->kh; ++i)
     for (int j = 0; j < d->kw; ++j) { Tap& t = a.taps[i * d->kw + j]; t.dy = (int8_t)(i - d->pad); t.dx = (int8_t)(j - d->pad); t.widx = (int16_t)(i * d->kw + j); }
-  int e = d->dtype == MI355_BF16 ? dispatch_gather<bf16_t>(a, as_stream(stream)) : dispatch_gather<float>(a, as_stream(stream));
+  int e;
+  if (f8) { a.scale2 = f8->descale_a; a.scale3 = f8->descale_b; a.a_fmt = f8->a_fmt; e = dispatch_gather_fp8(a, as_stream(stream)); }
+  else e = d->dtype == MI355_BF16 ? dispatch_gather<bf16_t>(a, as_stream(stream)) : dispatch_gather<float>(a, as_stream(stream));
   if (nslices) *nslices = a.stat_slices;
   return e;
+}
+extern "C" int mi355_conv_fwd_fp8(const mi355_conv_desc* d, const void* x8, int x_fmt, const void* w8, const float* descale_x,
+                                  const float* descale_w, const float* bias, const void* residual, void* y, float* partial,
+                                  size_t partial_bytes, int* nslices, void* stream) {
+  if (!descale_x || !descale_w || (x_fmt != 0 && x_fmt != 1)) MI_FAIL(MI355_EINVAL, "conv_fwd_fp8: descale scalars / format missing");
+  if (nslices) *nslices = 0;
+  Fp8Extra f8{descale_x, descale_w, x_fmt};
+  return conv_fwd_impl(d, x8, w8, bias, residual, y, partial, partial_bytes, nslices, stream, nullptr, &f8);
 }
 extern "C" int mi355_conv_fwd(const mi355_conv_desc* d, const void* x, const void* w, const float* bias,
                               const void* residual, void* y, void* stream) {
@@ -1327,7 +1287,14 @@ extern "C" int mi355_conv1x1_heatmap(const void* x, const void* w, const float* 
 // decomposed into stride^2 phases (iy%s, ix%s), each a unit-stride gather over its own tap subset.
 static int conv_dgrad_impl(const mi355_conv_desc* d, const void* dy, const void* wT, const float* bias, const float* scale_dev,
                            int accumulate, void* dx, float* partial, size_t partial_bytes, int* nslices, void* stream,
-                           const mi355_bn_bwd_src* bn = nullptr);
+                           const mi355_bn_bwd_src* bn = nullptr, const Fp8Extra* f8 = nullptr);
+extern "C" int mi355_conv_dgrad_fp8(const mi355_conv_desc* d, const void* dy8, int dy_fmt, const void* wT8, const float* descale_dy,
+                                    const float* descale_w, const float* scale_dev, int accumulate, void* dx, float* partial,
+                                    size_t partial_bytes, int* nslices, void* stream) {
+  if (!descale_dy || !descale_w || (dy_fmt != 0 && dy_fmt != 1)) MI_FAIL(MI355_EINVAL, "conv_dgrad_fp8: descale scalars / format missing");
+  Fp8Extra f8{descale_dy, descale_w, dy_fmt};
+  return conv_dgrad_impl(d, dy8, wT8, nullptr, scale_dev, accumulate, dx, partial, partial_bytes, nslices, stream, nullptr, &f8);
+}
 // conv input gradient that is the dy of a BatchNorm: that BatchNorm's backward reduction in the epilogue
 extern "C" int mi355_conv_dgrad_bnbwd(const mi355_conv_desc* d, const void* dy, const void* wT, const float* scale_dev, int accumulate,
                                       void* dx, const mi355_bn_bwd_src* bn, float* partial, size_t partial_bytes, int* nslices,
@@ -1347,12 +1314,14 @@ extern "C" int mi355_conv_dgrad_stats(const mi355_conv_desc* d, const void* dy, 
 }
 static int conv_dgrad_impl(const mi355_conv_desc* d, const void* dy, const void* wT, const float* bias, const float* scale_dev,
                            int accumulate, void* dx, float* partial, size_t partial_bytes, int* nslices, void* stream,
-                           const mi355_bn_bwd_src* bn) {
+                           const mi355_bn_bwd_src* bn, const Fp8Extra* f8) {
   if (nslices) *nslices = 0;
   if (int e = check_desc(d)) return e;
+  if ((d->dtype == MI355_FP8) != (f8 != nullptr)) MI_FAIL(MI355_EINVAL, "fp8 descriptors go through the *_fp8 entry points (and only they)");
+  if (f8 && bn) MI_FAIL(MI355_EINVAL, "fp8 dgrad: no BatchNorm-backward epilogue");
   hipStream_t st = as_stream(stream);
   const int s = d->stride;
-  const size_t esz = d->dtype == MI355_BF16 ? 2 : 4;
+  const size_t esz = d->dtype == MI355_F32 ? 4 : 2;        // dx element size (bf16 for fp8 operands)
   bool need_zero = false;
   for (int py = 0; py < s && !need_zero; ++py) {
     int cnt = 0; for (int kh = 0; kh < d->kh; ++kh) if ((py + d->pad - kh) % s == 0) ++cnt;
@@ -1399,10 +1368,13 @@ static int conv_dgrad_impl(const mi355_conv_desc* d, const void* dy, const void*
     // statistics only when every output pixel is produced by this launch (no zero-filled phase)
     if (bn) set_bnb(a, bn, partial, partial_bytes);   // (zero-filled phases carry dy = 0: they add nothing to the sums)
     else if (partial && !need_zero && a.nphase == s * s) { a.stat_partial = partial; a.stat_bytes = partial_bytes; }
-    int e = d->dtype == MI355_BF16 ? dispatch_gather<bf16_t>(a, st) : dispatch_gather<float>(a, st);
+    int e;
+    if (f8) { a.scale2 = f8->descale_a; a.scale3 = f8->descale_b; a.a_fmt = f8->a_fmt; e = dispatch_gather_fp8(a, st); }
+    else e = d->dtype == MI355_BF16 ? dispatch_gather<bf16_t>(a, st) : dispatch_gather<float>(a, st);
     if (nslices) *nslices = a.stat_slices;
     return e;
   }
+  if (f8) MI_FAIL(MI355_EINVAL, "fp8 dgrad: MI355_PHASES=0 is a bf16 / fp32 experiment switch");
   const int np = a.nphase;
   for (int i = 0; i < np; ++i) {
     GatherArgs b = a; b.nphase = 1; b.ph[0] = a.ph[i];

@@ -1,0 +1,67 @@
+// Argument block and device helpers shared by the implicit-GEMM gather kernels (igemm.hip: bf16 / fp32,
+// igemm_fp8.hip: fp8 operands with bf16 output).
+#pragma once
+#include "common.h"
+
+#define MAX_TAPS 52
+struct Tap { int8_t dy, dx; int16_t widx; };
+
+// One launch covers up to 4 independent sub-problems ("phases") that share A, B, D and the tile shape: the stride^2
+// output phases of a strided dgrad / ConvTranspose forward, each a unit-stride gather over its own tap subset.
+// Logical tile id = tile_in_phase * nphase + phase, so every XCD gets the same mix of light and heavy phases.
+struct Phase { int OHp, OWp, out_oy, out_ox, M, ntaps, tap0, ntm; };
+struct GatherArgs {
+  const void* A; const void* B; void* D;
+  const float* bias; const void* residual; const float* scale;
+  int Hi, Wi, Ci;
+  int in_sy, in_sx;
+  int Ho, Wo;
+  int out_sy, out_sx;
+  int Nout, ldb, ldd;
+  int cshift;
+  int accumulate;
+  int nphase, ntn, ntiles;     // ntiles = nphase * max_phase(ntm) * ntn
+  int hw;                      // heat-map output mode: pixels per image
+  int lw;                      // KW3: log2(min(W, 128))
+  unsigned a_bytes, b_bytes;
+  size_t stat_bytes;           // (host) capacity of stat_partial
+  int stat_slices;             // (host) slices the launch writes: nphase * ntm, 0 when the statistics were not fused
+  // BatchNorm BACKWARD reduction fused into the epilogue: this launch produces dy of a BatchNorm whose input was bnb_x
+  // (same shape as D); per m-tile slice and channel it leaves (sum dy_eff, sum dy_eff * xhat) in bnb_partial[slice][Nout][2].
+  // bnb_relu: 0 none, 1 mask from bnb_y > 0, 2 mask recomputed from bnb_x (see bn.hip).
+  const void* bnb_x; const void* bnb_y;
+  const float* bnb_mean; const float* bnb_invstd; const float* bnb_gamma; const float* bnb_beta;
+  float* bnb_partial; int bnb_relu;
+  float* stat_partial;         // BatchNorm statistics of the OUTPUT fused into the epilogue: [m-tile slice][Nout][n, mean, M2]
+  Phase ph[4];
+  Tap taps[MAX_TAPS];
+  const float* scale2;         // fp8 path: further device scalars multiplied into the output (operand descales)
+  const float* scale3;
+  int a_fmt;                   // fp8 path: format of the gathered operand, 0 = e4m3, 1 = e5m2
+};
+
+// swizzled byte offset of 16-byte chunk `c` (0..7) in 128-byte row `r`
+__device__ __forceinline__ int swz128(int r, int c) { return r * 128 + ((c ^ ((r >> 1) & 7)) << 4); }
+
+// XCD-aware bijective remap of the linear block id (blocks b and b+8 share an XCD / L2).
+__device__ __forceinline__ int xcd_remap(int bid, int nblk) {
+  int q = nblk >> 3, r = nblk & 7, x = bid & 7, i = bid >> 3;
+  int start = (x < r) ? x * (q + 1) : r * (q + 1) + (x - r) * q;
+  return start + i;
+}
+
+// 16-byte load through a buffer descriptor: out-of-range offsets (>= num_records) return zeros, so halo / tail
+// handling needs no branch and no zero-initialised destination.
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
+#define OOB_OFF ((int)0x80000000)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ uint4 buf_load16(__amdgpu_buffer_rsrc_t rs, int byte_off) {
+  u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(rs, byte_off, 0, 0);
+  return make_uint4(v[0], v[1], v[2], v[3]);
+}
+
+
+// fp8-operand build of the gather GEMM (igemm_fp8.hip).  `a` is filled exactly as for the bf16 kernel (element = byte).
+int dispatch_gather_fp8(GatherArgs& a, hipStream_t st);

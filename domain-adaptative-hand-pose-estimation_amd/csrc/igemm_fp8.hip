@@ -1,0 +1,428 @@
+// fp8 operand path of the implicit-GEMM convolution family (gfx950, OCP e4m3 / e5m2, fp32 accumulate, bf16 out).
+//
+// Why: the bf16 gather kernel is bounded by the bytes its tiles pull through the CU's vector-memory path per MFMA
+// (~0.5 KB / MFMA at a sustained ~15 TB/s of tile fills).  v_mfma_f32_32x32x16_fp8_fp8 has the
+// cycles of the bf16 instruction at the same K, so a 128-byte LDS row now carries 128 channels instead of 64: the same
+// staged bytes, the same ds_read_b128 stream, twice the MFMA work.  A lane's 16-byte fragment read feeds TWO MFMAs (low /
+// high 8 bytes); both operands use the same lane -> k assignment, so any k order is consistent.
+//
+// Also here: per-tensor scaled quantisation bf16 / fp32 -> fp8 with amax tracking (delayed scaling: quantise with the
+// scale derived from the previous amax while recording the current one; `mi355_fp8_amax` + `mi355_fp8_update_scale` give
+// the just-in-time form), and the fp8 weight pack ([O][T][I] and [I][T][O], per-tensor scale).
+#include "igemm_common.h"
+#include <stdlib.h>
+
+typedef long i64_t;
+
+// ------------------------------------------------------------------------------------ quantisation
+// state[0] = scale (x_q = x * scale), state[1] = descale = 1 / scale, state[2] = amax seen since the last update (bits)
+__device__ __forceinline__ float clamp_fp8(float v, float lim) {   // saturate; NaN stays NaN
+  return v != v ? v : fminf(fmaxf(v, -lim), lim);
+}
+template <bool BF8>
+__device__ __forceinline__ unsigned pack4_fp8(float a, float b, float c, float d) {
+  constexpr float LIM = BF8 ? 57344.f : 448.f;
+  int w = 0;
+  if constexpr (BF8) {
+    w = __builtin_amdgcn_cvt_pk_bf8_f32(clamp_fp8(a, LIM), clamp_fp8(b, LIM), w, false);
+    w = __builtin_amdgcn_cvt_pk_bf8_f32(clamp_fp8(c, LIM), clamp_fp8(d, LIM), w, true);
+  } else {
+    w = __builtin_amdgcn_cvt_pk_fp8_f32(clamp_fp8(a, LIM), clamp_fp8(b, LIM), w, false);
+    w = __builtin_amdgcn_cvt_pk_fp8_f32(clamp_fp8(c, LIM), clamp_fp8(d, LIM), w, true);
+  }
+  return (unsigned)w;
+}
+
+// 16 input elements per thread-iteration -> one 16-byte fp8 chunk.  amax over |x| (before scaling) into state[2] via an
+// integer atomic max on the float bits (exact and order-independent).
+template <typename T, bool BF8, bool WRITE>
+__global__ __launch_bounds__(256) void quantize_fp8_kernel(const T* __restrict__ x, unsigned char* __restrict__ q, float* __restrict__ state, long n16) {
+  constexpr int PER = Chunk<T>::N, NC = 16 / PER;
+  const float scale = state[0];
+  float amax = 0.f;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (long)gridDim.x * blockDim.x) {
+    float v[16];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      float w[PER]; Chunk<T>::load(x + i * 16 + c * PER, w);
+#pragma unroll
+      for (int e = 0; e < PER; ++e) v[c * PER + e] = w[e];
+    }
+#pragma unroll
+    for (int e = 0; e < 16; ++e) amax = fmaxf(amax, fabsf(v[e]));      // (fmaxf ignores NaN)
+    if constexpr (WRITE) {
+      uint4 o;
+      o.x = pack4_fp8<BF8>(v[0] * scale, v[1] * scale, v[2] * scale, v[3] * scale);
+      o.y = pack4_fp8<BF8>(v[4] * scale, v[5] * scale, v[6] * scale, v[7] * scale);
+      o.z = pack4_fp8<BF8>(v[8] * scale, v[9] * scale, v[10] * scale, v[11] * scale);
+      o.w = pack4_fp8<BF8>(v[12] * scale, v[13] * scale, v[14] * scale, v[15] * scale);
+      reinterpret_cast<uint4*>(q)[i] = o;
+    }
+  }
+  // one atomic per BLOCK, and only when it can still raise the recorded value: atomics on one address serialise at
+  // ~12 ns each (8192 wave-level atomics made this kernel take 100 us whatever the tensor size)
+  __shared__ float red[4];
+  amax = block_max<4>(amax, red);
+  if (threadIdx.x == 0 && amax > 0.f) {
+    const unsigned bits = __float_as_uint(amax);
+    unsigned* slot = reinterpret_cast<unsigned*>(state) + 2;
+    if (bits > __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(slot, bits);
+  }
+}
+
+// scale := fmt_max / (amax * 2^margin) (1 when nothing was seen yet), descale := 1 / scale, amax := 0.  `n` states.
+__global__ void fp8_update_scale_kernel(float* __restrict__ states, int n, int stride, float fmt_max, float margin_pow2) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float* s = states + (size_t)i * stride;
+  const float amax = __uint_as_float(reinterpret_cast<unsigned*>(s)[2]);
+  if (amax > 0.f && amax < 3.0e38f) {
+    // power-of-two scale: scaling / descaling are exact, only the fp8 rounding itself loses bits
+    const float raw = fmt_max / (amax * margin_pow2);
+    const float sc = exp2f(floorf(log2f(raw)));
+    s[0] = sc; s[1] = 1.0f / sc;
+  } else if (s[0] == 0.f) { s[0] = 1.f; s[1] = 1.f; }
+  reinterpret_cast<unsigned*>(s)[2] = 0u;
+}
+
+extern "C" int mi355_fp8_quantize(const void* x, void* q, float* state, long n, int src_dtype, int fmt, int write, void* stream) {
+  if (!x || !state || (write && !q) || n < 16 || n % 16) MI_FAIL(MI355_EINVAL, "fp8_quantize: n=%ld must be a positive multiple of 16", n);
+  if (fmt != 0 && fmt != 1) MI_FAIL(MI355_EINVAL, "fp8_quantize: fmt %d (0 = e4m3, 1 = e5m2)", fmt);
+  if (src_dtype != MI355_BF16 && src_dtype != MI355_F32) MI_FAIL(MI355_EINVAL, "fp8_quantize: source dtype %d", src_dtype);
+  const long n16 = n / 16;
+  int grid = (int)((n16 + 255) / 256); if (grid > 1024) grid = 1024;
+  hipStream_t st = as_stream(stream);
+  unsigned char* o = reinterpret_cast<unsigned char*>(q);
+#define MI_Q(T, BF8, W) hipLaunchKernelGGL((quantize_fp8_kernel<T, BF8, W>), dim3(grid), dim3(256), 0, st, (const T*)x, o, state, n16)
+  if (src_dtype == MI355_BF16) {
+    if (!write) MI_Q(bf16_t, false, false); else if (fmt) MI_Q(bf16_t, true, true); else MI_Q(bf16_t, false, true);
+  } else {
+    if (!write) MI_Q(float, false, false); else if (fmt) MI_Q(float, true, true); else MI_Q(float, false, true);
+  }
+#undef MI_Q
+  MI_CHECK_LAUNCH("fp8_quantize");
+  return MI355_OK;
+}
+
+extern "C" int mi355_fp8_update_scale(float* states, int n, int stride_floats, int fmt, int margin, void* stream) {
+  if (!states || n < 1 || stride_floats < 3 || (fmt != 0 && fmt != 1) || margin < 0 || margin > 8)
+    MI_FAIL(MI355_EINVAL, "fp8_update_scale: bad args");
+  hipLaunchKernelGGL(fp8_update_scale_kernel, dim3(cdiv(n, 64)), dim3(64), 0, as_stream(stream), states, n, stride_floats,
+                     fmt ? 57344.f : 448.f, (float)(1 << margin));
+  MI_CHECK_LAUNCH("fp8_update_scale");
+  return MI355_OK;
+}
+
+// fp32 master [O][T][I] (conv-form) -> e4m3 wf [O][T][I] and wt [I][T][O], both * state[0].  I, O multiples of 16.
+__global__ __launch_bounds__(256) void pack_weights_fp8_kernel(const float* __restrict__ w, unsigned char* __restrict__ wf,
+                                                                unsigned char* __restrict__ wt, const float* __restrict__ state,
+                                                                int O, int T, int I) {
+  __shared__ float tile[32][33];
+  __shared__ float red[4];
+  const float scale = state[0];
+  const int tiles_i = I / 32, tiles_o = O / 32;
+  const int b = blockIdx.x;
+  const int tap = b / (tiles_i * tiles_o), r = b % (tiles_i * tiles_o);
+  const int o0 = (r / tiles_i) * 32, i0 = (r % tiles_i) * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;            // 32 x 8
+  float amax = 0.f;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int o = o0 + ty + 8 * k;
+    const float v = w[((size_t)o * T + tap) * I + i0 + tx];
+    amax = fmaxf(amax, fabsf(v));
+    tile[ty + 8 * k][tx] = v * scale;
+  }
+  amax = block_max<4>(amax, red);                     // (contains the barriers that publish `tile`)
+  if (threadIdx.x == 0 && amax > 0.f) {               // amax of the master for the next scale update (delayed scaling)
+    const unsigned bits = __float_as_uint(amax);
+    unsigned* slot = reinterpret_cast<unsigned*>(const_cast<float*>(state)) + 2;
+    if (bits > __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(slot, bits);
+  }
+  __syncthreads();
+  // wf rows: 32 o x 32 i -> each thread packs 4 consecutive i of one o
+  {
+    const int o = threadIdx.x >> 3, g = threadIdx.x & 7;
+    const unsigned v = pack4_fp8<false>(tile[o][4 * g], tile[o][4 * g + 1], tile[o][4 * g + 2], tile[o][4 * g + 3]);
+    *reinterpret_cast<unsigned*>(wf + ((size_t)(o0 + o) * T + tap) * I + i0 + 4 * g) = v;
+  }
+  {
+    const int i = threadIdx.x >> 3, g = threadIdx.x & 7;
+    const unsigned v = pack4_fp8<false>(tile[4 * g][i], tile[4 * g + 1][i], tile[4 * g + 2][i], tile[4 * g + 3][i]);
+    *reinterpret_cast<unsigned*>(wt + ((size_t)(i0 + i) * T + tap) * O + o0 + 4 * g) = v;
+  }
+}
+
+extern "C" int mi355_pack_weights_fp8(const float* w_master, void* wf, void* wt, float* state, int O, int T, int I, int margin, void* stream) {
+  if (!w_master || !wf || !wt || !state || O < 32 || I < 32 || O % 32 || I % 32 || T < 1)
+    MI_FAIL(MI355_EINVAL, "pack_weights_fp8: O=%d I=%d must be multiples of 32 (T=%d)", O, I, T);
+  if (margin >= 0) {      // just-in-time scale from the amax of this very tensor (two more launches)
+    if (int e = mi355_fp8_quantize(w_master, nullptr, state, (long)O * T * I, MI355_F32, 0, 0, stream)) return e;   // amax only
+    if (int e = mi355_fp8_update_scale(state, 1, 4, 0, margin, stream)) return e;
+  }                       // margin < 0: the scale already in `state` (delayed scaling); the amax of w is recorded either way
+  hipLaunchKernelGGL(pack_weights_fp8_kernel, dim3((O / 32) * (I / 32) * T), dim3(256), 0, as_stream(stream), w_master,
+                     (unsigned char*)wf, (unsigned char*)wt, (const float*)state, O, T, I);
+  MI_CHECK_LAUNCH("pack_weights_fp8");
+  return MI355_OK;
+}
+
+// ------------------------------------------------------------------------------------ gather GEMM, fp8 operands
+template <int BM, int BN>
+struct Fp8Smem {
+  static constexpr int kStage = (BM + BN) * 128;
+  static constexpr int kOutStride = BN * 2 + 16;             // bf16 output tile rows
+  static constexpr int kOut = BM * kOutStride;
+  static constexpr int kBytes = (kStage > kOut ? kStage : kOut) + BM * 4;
+};
+
+// 4 waves (2 x 2), each a (BM/2) x (BN/2) sub-tile of 32x32 MFMA blocks.  K-tile = 128 channels of one tap
+// (8 chunks of 16 bytes); register-staged pipeline over one LDS stage, like the bf16 kernel's default path.
+// A_BF8: the gathered operand is e5m2 (gradients), the weights are always e4m3.  EPI 1: BatchNorm statistics of the output.
+template <int BM, int BN, bool A_BF8, int EPI>
+__global__ __launch_bounds__(256) void gather_fp8_kernel(const GatherArgs p) {
+  constexpr int CHI = 16;                                     // fp8 elements per 16-byte chunk
+  constexpr int CHO = 8;                                      // bf16 output elements per chunk
+  constexpr int NTHR = 256, RPP = 32;
+  constexpr int WM = BM / 2, WN = BN / 2, MT = WM / 32, NT = WN / 32;
+  constexpr int RA = BM / RPP, RB = BN / RPP;
+  using SM = Fp8Smem<BM, BN>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  int* row_off = reinterpret_cast<int*>(smem + SM::kBytes - BM * 4);
+
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int tile_g = xcd_remap(blockIdx.x, p.ntiles);
+  const int phi = tile_g % p.nphase, tile = tile_g / p.nphase;
+  const Phase& P = p.ph[phi];
+  if (tile >= P.ntm * p.ntn) return;
+  const int pM = P.M, pOHp = P.OHp, pOWp = P.OWp, pkchunks = P.ntaps << p.cshift;
+  const Tap* __restrict__ ptaps = p.taps + P.tap0;
+  const int m0 = (tile / p.ntn) * BM, n0 = (tile % p.ntn) * BN;
+  const int wm0 = (wave >> 1) * WM, wn0 = (wave & 1) * WN;
+  const int lc = t & 7, lr = t >> 3;
+  const __amdgpu_buffer_rsrc_t rsA = make_rsrc(p.A, p.a_bytes), rsB = make_rsrc(p.B, p.b_bytes);
+
+  int iy0[RA], ix0[RA], pix0[RA];
+#pragma unroll
+  for (int i = 0; i < RA; ++i) {
+    const int m = m0 + lr + RPP * i;
+    if (m < pM) {
+      const int ox = m % pOWp, r = m / pOWp, oy = r % pOHp, n = r / pOHp;
+      iy0[i] = oy * p.in_sy; ix0[i] = ox * p.in_sx;
+      pix0[i] = (n * p.Hi * p.Wi + iy0[i] * p.Wi + ix0[i]) * p.Ci;
+    } else { iy0[i] = -(1 << 20); ix0[i] = 0; pix0[i] = 0; }
+  }
+  if (t < BM) {
+    const int m = m0 + t; int off = -1;
+    if (m < pM) {
+      const int ox = m % pOWp, r = m / pOWp, oy = r % pOHp, n = r / pOHp;
+      off = ((n * p.Ho + oy * p.out_sy + P.out_oy) * p.Wo + ox * p.out_sx + P.out_ox) * p.ldd;
+    }
+    row_off[t] = off;
+  }
+  const int cmask = (1 << p.cshift) - 1;
+  uint4 ra0[RA], rb0[RB];
+  auto load_tile = [&](int kt, uint4 (&ra)[RA], uint4 (&rb)[RB]) {
+    const Tap tp = ptaps[(kt * 8) >> p.cshift];
+    const int cc = (((kt * 8) & cmask) + lc) * CHI;
+    const int toff = ((int)tp.dy * p.Wi + (int)tp.dx) * p.Ci + cc;
+    const int koff = (int)tp.widx * p.Ci + cc;
+#pragma unroll
+    for (int i = 0; i < RA; ++i) {
+      const int iy = iy0[i] + tp.dy, ix = ix0[i] + tp.dx;
+      const bool ok = (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
+      ra[i] = buf_load16(rsA, ok ? pix0[i] + toff : OOB_OFF);
+    }
+#pragma unroll
+    for (int i = 0; i < RB; ++i) {
+      const int n = n0 + lr + RPP * i;
+      rb[i] = buf_load16(rsB, n < p.Nout ? n * p.ldb + koff : OOB_OFF);
+    }
+  };
+  char* as = smem;
+  char* bs = smem + BM * 128;
+  f32x16_t acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  const int r31 = lane & 31, hi = lane >> 5;
+
+  const int nk = (pkchunks + 7) >> 3;
+  load_tile(0, ra0, rb0);
+  for (int kt = 0; kt < nk; ++kt) {
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < RA; ++i) *reinterpret_cast<uint4*>(as + swz128(lr + RPP * i, lc)) = ra0[i];
+#pragma unroll
+    for (int i = 0; i < RB; ++i) *reinterpret_cast<uint4*>(bs + swz128(lr + RPP * i, lc)) = rb0[i];
+    __syncthreads();
+    if (kt + 1 < nk) load_tile(kt + 1, ra0, rb0);
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      // one 16-byte read per fragment row = the operands of two MFMAs (k sets {chunk 2s+hi, bytes 0..7} and {.., 8..15})
+      uint4 a[MT], b[NT];
+#pragma unroll
+      for (int i = 0; i < MT; ++i) a[i] = *reinterpret_cast<const uint4*>(as + swz128(wm0 + i * 32 + r31, 2 * s + hi));
+#pragma unroll
+      for (int j = 0; j < NT; ++j) b[j] = *reinterpret_cast<const uint4*>(bs + swz128(wn0 + j * 32 + r31, 2 * s + hi));
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int j = 0; j < NT; ++j) {
+            const i64_t av = h ? (((i64_t)a[i].w << 32) | a[i].z) : (((i64_t)a[i].y << 32) | a[i].x);
+            const i64_t bv = h ? (((i64_t)b[j].w << 32) | b[j].z) : (((i64_t)b[j].y << 32) | b[j].x);
+            // operands swapped (weights first): acc holds D^T, lane = output pixel, registers = runs of 4 channels
+            if constexpr (A_BF8) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_fp8_bf8(bv, av, acc[i][j], 0, 0, 0);
+            else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(bv, av, acc[i][j], 0, 0, 0);
+          }
+    }
+    __builtin_amdgcn_s_setprio(0);
+  }
+  __syncthreads();
+
+  // ---- epilogue: (acc * descale [* lambda] + bias) -> bf16 -> LDS tile -> coalesced 16-byte rows (+residual / +dx)
+  char* outs = smem;
+  const float scale = (p.scale ? *p.scale : 1.0f) * (p.scale2 ? *p.scale2 : 1.0f) * (p.scale3 ? *p.scale3 : 1.0f);
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int ml = wm0 + i * 32 + r31;
+        const int nl = wn0 + j * 32 + 8 * g + 4 * hi;
+        union { bf16_t h[4]; uint2 q; } u;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float b = (p.bias && (n0 + nl + e) < p.Nout) ? p.bias[n0 + nl + e] : 0.f;
+          u.h[e] = (bf16_t)(acc[i][j][4 * g + e] * scale + b);
+        }
+        *reinterpret_cast<uint2*>(outs + ml * SM::kOutStride + nl * 2) = u.q;
+      }
+  __syncthreads();
+  constexpr int CPR = BN / CHO;
+  bf16_t* __restrict__ D = reinterpret_cast<bf16_t*>(p.D);
+  const bf16_t* __restrict__ R = reinterpret_cast<const bf16_t*>(p.residual);
+  float sn = 0.f, smean[CHO], sm2[CHO];
+#pragma unroll
+  for (int e = 0; e < CHO; ++e) { smean[e] = 0.f; sm2[e] = 0.f; }
+  for (int id = t; id < BM * CPR; id += NTHR) {
+    const int r = id / CPR, c = id % CPR;
+    const int off = row_off[r];
+    const int n = n0 + c * CHO;
+    if (off < 0 || n >= p.Nout) continue;
+    float v[CHO];
+    Chunk<bf16_t>::load(reinterpret_cast<const bf16_t*>(outs + r * SM::kOutStride + c * 16), v);
+    const size_t g = (size_t)off + n;
+    if constexpr (EPI == 1) {
+      sn += 1.f; const float inv = 1.f / sn;
+#pragma unroll
+      for (int e = 0; e < CHO; ++e) { const float d = v[e] - smean[e]; smean[e] += d * inv; sm2[e] += d * (v[e] - smean[e]); }
+    }
+    if (R) { float w[CHO]; Chunk<bf16_t>::load(R + g, w);
+#pragma unroll
+      for (int e = 0; e < CHO; ++e) v[e] += w[e]; }
+    if (p.accumulate) { float w[CHO]; Chunk<bf16_t>::load(D + g, w);
+#pragma unroll
+      for (int e = 0; e < CHO; ++e) v[e] += w[e]; }
+    Chunk<bf16_t>::store(D + g, v);
+  }
+  if constexpr (EPI == 1) {
+    // same fold as the bf16 kernel: row lanes of a wave by shuffle-down (lower lane = left operand), the four waves through
+    // LDS in wave order -> (n, mean, M2) per channel and m-tile slice, fixed order
+    constexpr int NW = NTHR / 64;
+    static_assert(CPR <= 32, "chunk columns of one tile row must fit half a wave");
+#pragma unroll
+    for (int o = CPR; o < 64; o <<= 1) {
+      const float nb = __shfl_down(sn, o, 64);
+      const float nt = sn + nb, f = nt > 0.f ? nb / nt : 0.f;
+#pragma unroll
+      for (int e = 0; e < CHO; ++e) {
+        const float mb = __shfl_down(smean[e], o, 64), vb = __shfl_down(sm2[e], o, 64);
+        const float d = mb - smean[e];
+        smean[e] += d * f; sm2[e] += vb + d * d * sn * f;
+      }
+      sn = nt;
+    }
+    __syncthreads();
+    float* sp = reinterpret_cast<float*>(smem);        // [NW][BN][3]
+    static_assert(NW * BN * 3 * 4 <= SM::kBytes - BM * 4, "statistics scratch must fit in the tile staging area");
+    if (lane < CPR) {
+      const int c = t % CPR;
+#pragma unroll
+      for (int e = 0; e < CHO; ++e) {
+        float* q = sp + ((size_t)wave * BN + c * CHO + e) * 3;
+        q[0] = sn; q[1] = smean[e]; q[2] = sm2[e];
+      }
+    }
+    __syncthreads();
+    if (t < BN && n0 + t < p.Nout) {
+      float n = 0.f, mean = 0.f, m2 = 0.f;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) {
+        const float* q = sp + ((size_t)w * BN + t) * 3;
+        const float nb = q[0];
+        if (nb > 0.f) { const float nt = n + nb, f = nb / nt, d = q[1] - mean; mean += d * f; m2 += q[2] + d * d * n * f; n = nt; }
+      }
+      const int slice = (tile / p.ntn) * p.nphase + phi;
+      float* out = p.stat_partial + ((size_t)slice * p.Nout + n0 + t) * 3;
+      out[0] = n; out[1] = mean; out[2] = m2;
+    }
+  }
+}
+
+template <int BM, int BN>
+static void launch_fp8(GatherArgs& a, hipStream_t st) {
+  constexpr int smem = Fp8Smem<BM, BN>::kBytes;
+  a.ntn = cdiv(a.Nout, BN);
+  int mx = 0;
+  for (int i = 0; i < a.nphase; ++i) { a.ph[i].ntm = cdiv(a.ph[i].M, BM); if (a.ph[i].ntm > mx) mx = a.ph[i].ntm; }
+  a.ntiles = a.nphase * mx * a.ntn;
+  a.stat_slices = 0;
+  if (a.stat_partial) {
+    bool even = !a.residual && !a.accumulate;
+    for (int i = 0; i < a.nphase; ++i) even = even && a.ph[i].ntm == mx;
+    if (even && (size_t)a.nphase * mx * a.Nout * 3 * sizeof(float) <= a.stat_bytes) a.stat_slices = a.nphase * mx;
+    else a.stat_partial = nullptr;
+  }
+#define MI_L(BF8, EPI) do { auto kern = gather_fp8_kernel<BM, BN, BF8, EPI>; static bool set_ = false; \
+    if (!set_) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem); set_ = true; } \
+    hipLaunchKernelGGL(kern, dim3(a.ntiles), dim3(256), smem, st, a); } while (0)
+  if (a.a_fmt) { if (a.stat_partial) MI_L(true, 1); else MI_L(true, 0); }
+  else { if (a.stat_partial) MI_L(false, 1); else MI_L(false, 0); }
+#undef MI_L
+}
+
+static int ilog2x(int v) { int s = 0; while ((1 << s) < v) ++s; return ((1 << s) == v) ? s : -1; }
+
+int dispatch_gather_fp8(GatherArgs& a, hipStream_t st) {
+  if (a.Ci % 128) MI_FAIL(MI355_EINVAL, "fp8 gather: the contraction channels (%d) must be a multiple of 128", a.Ci);
+  a.cshift = ilog2x(a.Ci / 16);
+  if (a.cshift < 3) MI_FAIL(MI355_EINVAL, "fp8 gather: Ci/16 must be a power of two >= 8 (Ci=%d)", a.Ci);
+  if (a.Nout % 8) MI_FAIL(MI355_EINVAL, "fp8 gather: Nout=%d not a multiple of 8", a.Nout);
+  if (a.nphase < 1 || a.nphase > 4) MI_FAIL(MI355_EINVAL, "fp8 gather: nphase=%d", a.nphase);
+  if (a.bnb_partial) MI_FAIL(MI355_EINVAL, "fp8 gather: no BatchNorm-backward epilogue in this build");
+  long Mtot = 0, ntaps_tot = 0; double flops = 0.0;
+  for (int i = 0; i < a.nphase; ++i) {
+    Mtot += a.ph[i].M; ntaps_tot += a.ph[i].ntaps;
+    flops += 2.0 * a.ph[i].M * (double)a.Nout * a.ph[i].ntaps * a.Ci;
+  }
+  const long imgs = a.ph[0].M / ((long)a.ph[0].OHp * a.ph[0].OWp);
+  const long abytes = imgs * a.Hi * a.Wi * a.Ci, bbytes = (long)a.Nout * a.ldb;
+  if (abytes >= (1L << 31) || bbytes >= (1L << 31) || Mtot * a.Nout * 2 >= (1L << 31))
+    MI_FAIL(MI355_EINVAL, "fp8 gather: tensor too large for 32-bit byte offsets");
+  a.a_bytes = (unsigned)abytes; a.b_bytes = (unsigned)bbytes;
+  ProfScope ps(st, flops, (double)abytes + (double)bbytes * ntaps_tot / (a.ldb / a.Ci) + (double)Mtot * a.Nout * 2);
+  static const int force = getenv("MI355_FP8_TILE") ? atoi(getenv("MI355_FP8_TILE")) : -1;
+  const long t128 = cdiv(Mtot, 128L) * cdiv(a.Nout, 128);
+  if (force == 0 || (force < 0 && t128 >= 512 && a.Nout > 64)) launch_fp8<128, 128>(a, st);
+  else if (force == 1 || (force < 0 && a.Nout > 64 && cdiv(Mtot, 64L) * cdiv(a.Nout, 128) >= 256)) launch_fp8<64, 128>(a, st);
+  else launch_fp8<64, 64>(a, st);
+  MI_CHECK_LAUNCH("gather_fp8");
+  return MI355_OK;
+}

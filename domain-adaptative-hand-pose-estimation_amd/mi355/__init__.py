@@ -9,7 +9,7 @@ import threading
 
 import torch
 
-F32, BF16 = 0, 1
+F32, BF16, FP8 = 0, 1, 2
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), 'libmi355pose.so')
 
@@ -45,6 +45,11 @@ SIGNATURES = {
     'mi355_conv_dgrad_stats': (_I, [_D, _P, _P, _P, _P, _Z, _P, _P]),
     'mi355_conv_dgrad_bnbwd': (_I, [_D, _P, _P, _P, _I, _P, _P, _P, _Z, _P, _P]),
     'mi355_conv_fwd_bnbwd': (_I, [_D, _P, _P, _P, _P, _P, _Z, _P, _P]),
+    'mi355_fp8_quantize': (_I, [_P, _P, _P, _L, _I, _I, _I, _P]),
+    'mi355_fp8_update_scale': (_I, [_P, _I, _I, _I, _I, _P]),
+    'mi355_pack_weights_fp8': (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    'mi355_conv_fwd_fp8': (_I, [_D, _P, _I, _P, _P, _P, _P, _P, _P, _P, _Z, _P, _P]),
+    'mi355_conv_dgrad_fp8': (_I, [_D, _P, _I, _P, _P, _P, _P, _I, _P, _P, _Z, _P, _P]),
     'mi355_conv_wgrad_workspace': (_Z, [_D]),
     'mi355_conv_wgrad': (_I, [_D, _P, _P, _P, _I, _P, _Z, _P]),
     'mi355_pack_weights': (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
@@ -128,19 +133,59 @@ def ptr(t):
 _compute_dtype = torch.bfloat16
 
 
+_fp8_convs = False
+
+
 def set_compute_dtype(dt):
-    """'bf16' (default, throughput path) or 'f32' (exact-fp32 MFMA parity path)."""
-    global _compute_dtype
+    """'bf16' (default, throughput path), 'f32' (exact-fp32 MFMA parity path) or 'fp8': bf16 storage and kernels
+    everywhere, except that the forward and input-gradient GEMMs of the K-heavy convolutions (3x3 / 4x4, channel counts
+    that are multiples of 128) run on fp8 operands (e4m3 activations and weights, e5m2 gradients, per-tensor delayed
+    scaling, fp32 accumulate); weight gradients stay bf16."""
+    global _compute_dtype, _fp8_convs
     if dt in ('bf16', torch.bfloat16):
-        _compute_dtype = torch.bfloat16
+        _compute_dtype, _fp8_convs = torch.bfloat16, False
     elif dt in ('f32', 'fp32', torch.float32):
-        _compute_dtype = torch.float32
+        _compute_dtype, _fp8_convs = torch.float32, False
+    elif dt in ('fp8', 'f8'):
+        _compute_dtype, _fp8_convs = torch.bfloat16, True
     else:
-        raise ValueError('compute dtype must be bf16 or f32, got %r' % (dt,))
+        raise ValueError('compute dtype must be bf16, f32 or fp8, got %r' % (dt,))
 
 
 def compute_dtype():
+    """Storage / kernel dtype of activations (bf16 in 'fp8' mode as well)."""
     return _compute_dtype
+
+
+def fp8_convs():
+    return _fp8_convs
+
+
+# ---------------------------------------------------------------- fp8 scaling states (delayed scaling)
+# Every fp8 operand stream (one per conv input, one per conv output gradient) owns a 4-float device record
+# {scale, descale, amax bits, pad} carved out of one pool per format, so that ONE launch per format refreshes every
+# scale from the amax values recorded since the last refresh (`fp8_tick`, called once per optimizer step).
+_FP8_POOL_SLOTS = 2048
+_fp8_pools = {}
+
+
+def fp8_alloc_state(device, fmt):
+    key = (device.index if device.index is not None else torch.cuda.current_device(), int(fmt))
+    pool = _fp8_pools.get(key)
+    if pool is None:
+        pool = _fp8_pools[key] = dict(buf=torch.zeros(_FP8_POOL_SLOTS * 4, dtype=torch.float32, device=device), used=0, fmt=int(fmt))
+    if pool['used'] >= _FP8_POOL_SLOTS:
+        raise Mi355Error('fp8 scaling-state pool exhausted')
+    i = pool['used']
+    pool['used'] += 1
+    return pool['buf'][4 * i: 4 * i + 4]
+
+
+def fp8_tick():
+    """Derive every fp8 scale from the amax recorded since the previous tick (delayed scaling); one launch per format."""
+    for pool in _fp8_pools.values():
+        if pool['used']:
+            call('mi355_fp8_update_scale', ptr(pool['buf']), pool['used'], 4, pool['fmt'], 0, stream_ptr())
 
 
 def dtype_code(dt):

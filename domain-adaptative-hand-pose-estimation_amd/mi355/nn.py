@@ -85,6 +85,55 @@ class _PackedWeights:
         return self.wf, self.wt
 
 
+class _PackedFp8:
+    """e4m3 copies ([O][T][I] forward operand, [I][T][O] input-gradient operand) of one conv-form weight with their
+    per-tensor scale, refreshed when the master changes (just-in-time scale: the weights are small)."""
+
+    def __init__(self):
+        self.key = None
+        self.wf = self.wt = self.state = None
+
+    def get(self, weight, O, T, I):
+        key = (_param_version(weight), O, T, I)
+        if key != self.key:
+            first = self.wf is None or self.wf.numel() != O * T * I or self.wf.device != weight.device
+            if first:
+                if torch.cuda.is_current_stream_capturing():
+                    raise Mi355Error('fp8 weight copies are created on first use: run one eager iteration before capturing')
+                self.wf = torch.empty(O * T * I, dtype=torch.uint8, device=weight.device)
+                self.wt = torch.empty(O * T * I, dtype=torch.uint8, device=weight.device)
+                self.state = _rt.fp8_alloc_state(weight.device, ops.E4M3)
+            # first pack: scale from this tensor; afterwards delayed scaling (weights move by lr per step): ONE launch
+            ops.pack_weights_fp8(weight.detach(), O, T, I, self.state, self.wf, self.wt, jit=first)
+            self.key = key
+        return self.wf, self.wt, self.state
+
+
+class _Fp8Stream:
+    """Scaling state of one fp8 operand stream (a conv's input or output gradient): the first tensor is scaled just in
+    time, later ones with the scale derived from the amax of the previous uses (mi355.fp8_tick)."""
+
+    def __init__(self, fmt):
+        self.fmt, self.state = fmt, None
+
+    def quantize(self, t):
+        # several convs read the same tensor (the neck output feeds three fp8 convs): quantise it once
+        hit = getattr(t, '_mi_q8', None)
+        if hit is not None and hit[2] == self.fmt and hit[3] == t._version:
+            return hit[0], hit[1]
+        q, st = self._quantize(t)
+        t._mi_q8 = (q, st, self.fmt, t._version)
+        return q, st
+
+    def _quantize(self, t):
+        first = self.state is None or self.state.device != t.device
+        if first:
+            if torch.cuda.is_current_stream_capturing():
+                raise Mi355Error('fp8 scaling state is created on first use: run one eager iteration before capturing')
+            self.state = _rt.fp8_alloc_state(t.device, self.fmt)
+        return ops.fp8_quantize(t, self.state, self.fmt, jit=first), self.state
+
+
 _PACK_BATCHED = __import__('os').environ.get('MI355_PACK_BATCHED', '1') == '1'
 
 
@@ -190,12 +239,22 @@ def _take_partial(mod, y):
 class _ConvFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, residual, mod, scale_dev, fan=None):
-        desc, wf, _ = mod._plan(x)
         ctx.fan = fan
-        if mod._want_stats() and residual is None:
-            y, mod._last_partial = ops.conv_fwd_stats(desc, x, wf, bias)
+        ctx.fp8 = mod._fp8_ok(x)
+        if ctx.fp8:
+            desc, desc8, wf8, _, sw = mod._plan_fp8(x)
+            x8, sx = mod._q_in.quantize(x)
+            want = mod._want_stats() and residual is None
+            y = ops.conv_fwd_fp8(desc8, x8, sx, wf8, sw, bias, residual, want_stats=want)
+            if want:
+                y, mod._last_partial = y
+            ctx.desc8 = desc8
         else:
-            y = ops.conv_fwd(desc, x, wf, bias, residual)
+            desc, wf, _ = mod._plan(x)
+            if mod._want_stats() and residual is None:
+                y, mod._last_partial = ops.conv_fwd_stats(desc, x, wf, bias)
+            else:
+                y = ops.conv_fwd(desc, x, wf, bias, residual)
         ctx.mod, ctx.desc, ctx.scale_dev = mod, desc, scale_dev
         ctx.bn_src = mod._in_bn_src; mod._in_bn_src = None
         ctx.has_bias = bias is not None
@@ -211,14 +270,21 @@ class _ConvFn(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             mod._wgrad(desc, x, dy, weight)          # off the critical path: side stream
         if ctx.needs_input_grad[0]:
-            _, _, wt = mod._plan(x)
             fan = ctx.fan
-            if fan is not None and fan.buf is not None and fan.buf.shape == x.shape and fan.buf.dtype == x.dtype:
-                _dgrad_for_bn(desc, dy, wt, ctx.bn_src, x, scale_dev=ctx.scale_dev, out=fan.buf, accumulate=True)
+            onto = fan is not None and fan.buf is not None and fan.buf.shape == x.shape and fan.buf.dtype == x.dtype
+            if ctx.fp8:
+                _, _, _, wt8, sw = mod._plan_fp8(x)
+                dy8, sdy = mod._q_dy.quantize(dy)
+                dx = ops.conv_dgrad_fp8(ctx.desc8, dy8, sdy, wt8, sw, scale_dev=ctx.scale_dev, out=fan.buf if onto else None,
+                                        accumulate=onto)
             else:
-                dx = _dgrad_for_bn(desc, dy, wt, ctx.bn_src, x, scale_dev=ctx.scale_dev)
-                if fan is not None:
-                    fan.buf = dx
+                _, _, wt = mod._plan(x)
+                dx = _dgrad_for_bn(desc, dy, wt, ctx.bn_src, x, scale_dev=ctx.scale_dev, out=fan.buf if onto else None,
+                                   accumulate=onto)
+            if onto:
+                dx = None
+            elif fan is not None:
+                fan.buf = dx
         if ctx.has_bias and ctx.needs_input_grad[2]:
             g, acc = grad_slot(bias)
             ops.colsum(dy, g, acc)
@@ -267,11 +333,20 @@ class _DeconvFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, mod):
-        desc, wf, wt = mod._plan(x)
-        if mod._want_stats():
-            y, mod._last_partial = ops.conv_dgrad_stats(desc, x, wt)
+        ctx.fp8 = mod._fp8_ok(x)
+        if ctx.fp8:      # conv-form dgrad with the deconv input as the gathered (e4m3) operand
+            desc, desc8, _, wt8, sw = mod._plan_fp8(x)
+            x8, sx = mod._q_in.quantize(x)
+            y = ops.conv_dgrad_fp8(desc8, x8, sx, wt8, sw, want_stats=mod._want_stats(), dy_fmt=ops.E4M3)
+            if mod._want_stats():
+                y, mod._last_partial = y
+            ctx.desc8 = desc8
         else:
-            y = ops.conv_dgrad(desc, x, wt)
+            desc, wf, wt = mod._plan(x)
+            if mod._want_stats():
+                y, mod._last_partial = ops.conv_dgrad_stats(desc, x, wt)
+            else:
+                y = ops.conv_dgrad(desc, x, wt)
         ctx.mod, ctx.desc = mod, desc
         ctx.bn_src = mod._in_bn_src; mod._in_bn_src = None
         ctx.save_for_backward(x, weight)
@@ -290,7 +365,11 @@ class _DeconvFn(torch.autograd.Function):
                     ops.conv_wgrad(desc, dy, x, g, acc, ws_tag='side')      # conv-form input = dy, conv-form output = x
             else:
                 ops.conv_wgrad(desc, dy, x, g, acc)
-        if ctx.needs_input_grad[0]:
+        if ctx.needs_input_grad[0] and ctx.fp8:
+            _, _, wf8, _, sw = mod._plan_fp8(x)
+            dy8, sdy = mod._q_dy.quantize(dy)
+            dx = ops.conv_fwd_fp8(ctx.desc8, dy8, sdy, wf8, sw, x_fmt=ops.E5M2)
+        elif ctx.needs_input_grad[0]:
             _, wf, _ = mod._plan(x)
             if ctx.bn_src is None:
                 dx = ops.conv_fwd(desc, dy, wf)
@@ -481,6 +560,7 @@ class Conv2d(nn.Module):
         self.weight = _convform_param(out_channels, in_channels, k, k)
         self.bias = nn.Parameter(torch.empty(out_channels)) if bias else None
         self._packed = _PackedWeights()
+        self._packed8, self._q_in, self._q_dy = _PackedFp8(), _Fp8Stream(ops.E4M3), _Fp8Stream(ops.E5M2)
         self._cast = _CastCopy()
         self._cast_t = _CastCopy(transposed=True)
         self._stem_tmp = None
@@ -527,6 +607,21 @@ class Conv2d(nn.Module):
         wf, wt = self._packed.get(self.weight, self.out_channels, k * k, self.in_channels, Cp, x.dtype)
         return desc, wf, wt
 
+    def _fp8_ok(self, x):
+        """fp8 operands for this conv?  'fp8' compute mode, a K-heavy kernel (3x3 and up: the 1x1 convs are HBM-bound, an
+        extra quantisation pass would cost more than the GEMM gains) and channel counts the fp8 K tile (128) divides."""
+        return (_rt.fp8_convs() and self.mode == 'mfma' and self.kernel_size[0] >= 3 and x.dtype == torch.bfloat16 and
+                self.in_channels % 128 == 0 and self.out_channels % 128 == 0)
+
+    def _plan_fp8(self, x):
+        N, C, H, W = x.shape
+        k = self.kernel_size[0]
+        _chk_convform(self.weight)
+        desc = ops.make_desc(N, H, W, C, self.out_channels, k, k, self.stride[0], self.padding[0], x.dtype)
+        desc8 = ops.make_desc_fp8(N, H, W, C, self.out_channels, k, k, self.stride[0], self.padding[0])
+        wf8, wt8, sw = self._packed8.get(self.weight, self.out_channels, k * k, self.in_channels)
+        return desc, desc8, wf8, wt8, sw
+
     def _wgrad(self, desc, x, dy, weight):
         g, acc = grad_slot(weight)
         if desc.Ci == self.in_channels:
@@ -571,7 +666,8 @@ class Conv2d(nn.Module):
     def forward_skip(self, x):
         """(conv(x), alias of x): for residual blocks, see _ConvSkipFn.  Bias-free MFMA convs only."""
         if not _SKIP_FUSE or self.mode != 'mfma' or self.bias is not None or getattr(x, '_mi_gl', None) is not None or \
-                self.in_channels != self._cin_pad(compute_dtype()):
+                self.in_channels != self._cin_pad(compute_dtype()) or \
+                (_rt.fp8_convs() and self.kernel_size[0] >= 3 and self.in_channels % 128 == 0 and self.out_channels % 128 == 0):
             return self.forward(x), x
         x = _as_feature(x, compute_dtype())
         self._in_bn_src = _bn_src_of(x)
@@ -592,10 +688,24 @@ class ConvTranspose2d(nn.Module):
         self.weight = _convform_param(in_channels, out_channels, kernel_size, kernel_size)
         self.bias = None
         self._packed = _PackedWeights()
+        self._packed8, self._q_in, self._q_dy = _PackedFp8(), _Fp8Stream(ops.E4M3), _Fp8Stream(ops.E5M2)
         self._last_partial = None
         self._in_bn_src = None
         self.bn_follows = False
         nn.init.kaiming_uniform_(self.weight, a=math.sqrt(5))
+
+    def _fp8_ok(self, x):
+        return (_rt.fp8_convs() and x.dtype == torch.bfloat16 and self.in_channels % 128 == 0 and self.out_channels % 128 == 0)
+
+    def _plan_fp8(self, x):
+        N, C, H, W = x.shape          # conv-form output side
+        k, s, p = self.kernel_size[0], self.stride[0], self.padding[0]
+        Hi, Wi = (H - 1) * s - 2 * p + k, (W - 1) * s - 2 * p + k
+        _chk_convform(self.weight)
+        desc = ops.make_desc(N, Hi, Wi, self.out_channels, self.in_channels, k, k, s, p, x.dtype)
+        desc8 = ops.make_desc_fp8(N, Hi, Wi, self.out_channels, self.in_channels, k, k, s, p)
+        wf8, wt8, sw = self._packed8.get(self.weight, self.in_channels, k * k, self.out_channels)
+        return desc, desc8, wf8, wt8, sw
 
     def _plan(self, x):
         N, C, H, W = x.shape          # x = conv-form OUTPUT (N, Co=in_channels, Ho, Wo)

@@ -8,7 +8,7 @@ import ctypes
 
 import torch
 
-from . import (BnBwdSrc, ConvDesc, Mi355Error, call, compute_dtype, dtype_code, load, ptr, stream_ptr, workspace)
+from . import (BnBwdSrc, ConvDesc, FP8, Mi355Error, call, compute_dtype, dtype_code, load, ptr, stream_ptr, workspace)
 
 
 # ---------------------------------------------------------------- layout helpers
@@ -168,6 +168,88 @@ def colsum(dy, out, accumulate):
     ws = workspace(load().mi355_colsum_workspace(rows, C), dy.device)
     call('mi355_colsum', ptr(dy), ptr(out), rows, C, dtype_code(dy.dtype), int(accumulate), ptr(ws), ws.numel(),
          stream_ptr())
+
+
+# ---------------------------------------------------------------- fp8 operand path (conv forward / input gradient)
+E4M3, E5M2 = 0, 1
+FP8_MARGIN = 0          # scale = 2^floor(log2(fmt_max / (amax * 2^margin)))
+
+
+def fp8_state(device):
+    """{scale, descale, amax bits, pad} of one per-tensor scaled fp8 operand (device floats)."""
+    return torch.zeros(4, dtype=torch.float32, device=device)
+
+
+def fp8_amax(x, state):
+    _chk_dev(x, state)
+    call('mi355_fp8_quantize', ptr(x), 0, ptr(state), x.numel(), dtype_code(x.dtype), 0, 0, stream_ptr())
+
+
+def fp8_update_scale(states, n=1, fmt=E4M3, margin=None):
+    call('mi355_fp8_update_scale', ptr(states), int(n), 4, int(fmt), FP8_MARGIN if margin is None else int(margin), stream_ptr())
+
+
+def fp8_quantize(x, state, fmt=E4M3, jit=False):
+    """bf16 / fp32 device tensor (any dense layout) -> uint8 tensor of the same shape and strides holding
+    saturate_fmt(x * state[0]).  jit=True: first take amax(|x|) and derive the scale from it (one extra read of x);
+    otherwise the scale already in `state` is used and the amax of x is recorded for the next update (delayed scaling)."""
+    _chk_dev(x, state)
+    if not (x.is_contiguous() or x.is_contiguous(memory_format=torch.channels_last)):
+        raise Mi355Error('fp8_quantize needs a dense tensor')
+    if x.numel() % 16:
+        raise Mi355Error('fp8_quantize needs a multiple of 16 elements, got %d' % x.numel())
+    if jit:
+        fp8_amax(x, state)
+        fp8_update_scale(state, 1, fmt)
+    q = torch.empty_like(x, dtype=torch.uint8)
+    call('mi355_fp8_quantize', ptr(x), ptr(q), ptr(state), x.numel(), dtype_code(x.dtype), int(fmt), 1, stream_ptr())
+    return q
+
+
+def pack_weights_fp8(w_master, O, T, I, state, wf=None, wt=None, jit=True):
+    """fp32 master in [O][T][I] memory order -> e4m3 (wf [O][T][I], wt [I][T][O]); jit: per-tensor scale from this very
+    tensor (3 launches), else the scale already in `state` (1 launch; the amax is recorded for the next update)."""
+    _chk_dev(w_master, state)
+    dev = w_master.device
+    wf = torch.empty(O * T * I, dtype=torch.uint8, device=dev) if wf is None else wf
+    wt = torch.empty(O * T * I, dtype=torch.uint8, device=dev) if wt is None else wt
+    call('mi355_pack_weights_fp8', ptr(w_master), ptr(wf), ptr(wt), ptr(state), O, T, I, FP8_MARGIN if jit else -1, stream_ptr())
+    return wf, wt
+
+
+def make_desc_fp8(N, Hi, Wi, Ci, Co, kh, kw, stride, pad):
+    Ho = (Hi + 2 * pad - kh) // stride + 1
+    Wo = (Wi + 2 * pad - kw) // stride + 1
+    return ConvDesc(N, Hi, Wi, Ci, Ho, Wo, Co, kh, kw, stride, pad, FP8)
+
+
+def conv_fwd_fp8(desc, x8, x_state, w8, w_state, bias=None, residual=None, want_stats=False, x_fmt=E4M3):
+    """y (bf16, channels_last) = conv(x8, w8) * descale_x * descale_w + bias (+ residual); optionally the BatchNorm
+    statistics partials of y.  Returns y or (y, (partial, nslices) | None)."""
+    _chk_dev(x8, w8)
+    y = nhwc_empty(desc.N, desc.Co, desc.Ho, desc.Wo, torch.bfloat16, x8.device)
+    partial, nbytes, ns = None, 0, ctypes.c_int(0)
+    if want_stats:
+        partial, nbytes = _stats_buf(desc.N * desc.Ho * desc.Wo, desc.Co, x8.device)
+    call('mi355_conv_fwd_fp8', ctypes.byref(desc), ptr(x8), int(x_fmt), ptr(w8), ptr(x_state[1:2]), ptr(w_state[1:2]), ptr(bias),
+         ptr(residual), ptr(y), ptr(partial), nbytes, ctypes.byref(ns), stream_ptr())
+    if want_stats:
+        return y, ((partial, ns.value) if ns.value > 0 else None)
+    return y
+
+
+def conv_dgrad_fp8(desc, dy8, dy_state, wT8, w_state, scale_dev=None, out=None, accumulate=False, want_stats=False, dy_fmt=E5M2):
+    """dx (bf16) = dgrad(dy8, wT8) * descale_dy * descale_w (* *scale_dev) (+ dx when accumulate)."""
+    _chk_dev(dy8, wT8)
+    dx = out if out is not None else nhwc_empty(desc.N, desc.Ci, desc.Hi, desc.Wi, torch.bfloat16, dy8.device)
+    partial, nbytes, ns = None, 0, ctypes.c_int(0)
+    if want_stats:
+        partial, nbytes = _stats_buf(desc.N * desc.Hi * desc.Wi, desc.Ci, dy8.device)
+    call('mi355_conv_dgrad_fp8', ctypes.byref(desc), ptr(dy8), int(dy_fmt), ptr(wT8), ptr(dy_state[1:2]), ptr(w_state[1:2]),
+         ptr(scale_dev), int(accumulate), ptr(dx), ptr(partial), nbytes, ctypes.byref(ns), stream_ptr())
+    if want_stats:
+        return dx, ((partial, ns.value) if ns.value > 0 else None)
+    return dx
 
 
 # ---------------------------------------------------------------- batch norm

@@ -176,6 +176,8 @@ class FusedSGD(Optimizer):
                 if not st:
                     p._mi_epoch = getattr(p, '_mi_epoch', 0) + 1
             repack_params(f['params'], f.setdefault('pack_cache', {}))     # packed conv copies: one launch per group
+        if _rt.fp8_convs():
+            _rt.fp8_tick()           # delayed scaling: the fp8 scales of the next pass from the amax values of this one
         return loss
 
     def load_state_dict(self, state_dict):

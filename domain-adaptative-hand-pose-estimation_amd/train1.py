@@ -387,7 +387,7 @@ _OPTIONS = [
     (('--ema-decay',), dict(default=0.999, type=float, metavar='ALPHA', help='unused (reference CLI parity)')),
     # additive
     (('--synthetic',), dict(action='store_true', help='seeded synthetic batches instead of the CPU dataset layer')),
-    (('--dtype',), dict(default='bf16', choices=['bf16', 'f32'], help='compute dtype of activations / packed weights')),
+    (('--dtype',), dict(default='bf16', choices=['bf16', 'f32', 'fp8'], help="compute dtype of activations / packed weights ('fp8': bf16 storage, fp8 operands in the K-heavy conv GEMMs)")),
     (('--no-graph',), dict(action='store_true', help='launch kernels eagerly instead of replaying HIP graphs')),
 ]
 

@@ -37,6 +37,7 @@ extern "C" {
 
 #define MI355_F32 0
 #define MI355_BF16 1
+#define MI355_FP8 2   /* conv descriptors of the *_fp8 entry points only: fp8 operands, fp32 accumulate, bf16 results */
 
 #define MI355_OK 0
 #define MI355_EINVAL (-1)   /* bad argument / unsupported shape */
@@ -47,7 +48,7 @@ typedef struct {
   int N, Hi, Wi, Ci; /* conv-form input  (NHWC)                       */
   int Ho, Wo, Co;    /* conv-form output (NHWC)                       */
   int kh, kw, stride, pad;
-  int dtype;         /* MI355_F32 | MI355_BF16 (activations+packed weights) */
+  int dtype;         /* MI355_F32 | MI355_BF16 (activations+packed weights) | MI355_FP8 (mi355_conv_*_fp8 only) */
 } mi355_conv_desc;
 
 int mi355_version(void);
@@ -92,6 +93,31 @@ int mi355_conv_dgrad_bnbwd(const mi355_conv_desc* d, const void* dy, const void*
                            void* stream);
 int mi355_conv_fwd_bnbwd(const mi355_conv_desc* d, const void* x, const void* w, void* y, const mi355_bn_bwd_src* bn,
                          float* partial, size_t partial_bytes, int* nslices, void* stream);
+/* ---- fp8 operand path (BASELINE config 5: "fp8 conv MFMA path"; reference layers: the K-heavy 3x3 / 4x4 convolutions
+ * of uda/model/regda_7.py:4906-4929, pose_resnet2.py:33-41 and the torchvision Bottleneck 3x3).  OCP formats:
+ * fmt 0 = e4m3 (activations, weights), fmt 1 = e5m2 (gradients).  Per-tensor scaling state = 4 floats on the device:
+ * {scale, descale = 1/scale, amax bits (max |x| seen since the last update), unused}.
+ *
+ * mi355_fp8_quantize: q[i] = saturate_fmt(x[i] * state[0]) for i < n (n a multiple of 16; x bf16 or fp32), and
+ *   state[2] = max(state[2], max |x|) -- with write = 0 only the amax is taken (just-in-time scaling: amax, update, quantise).
+ * mi355_fp8_update_scale: for each of n states (stride_floats apart): scale = 2^floor(log2(fmt_max / (amax * 2^margin)))
+ *   (kept when no amax was recorded; 1 if never set), descale = 1/scale, amax = 0.
+ * mi355_pack_weights_fp8: fp32 master [O][T][I] -> e4m3 wf [O][T][I] and wt [I][T][O] (O, I multiples of 32).  margin >= 0:
+ *   just-in-time per-tensor scale from amax(|w|), left in `state`; margin < 0: the scale already in `state` (delayed
+ *   scaling).  Either way amax(|w|) is recorded in state[2] for the next mi355_fp8_update_scale. */
+int mi355_fp8_quantize(const void* x, void* q, float* state, long n, int src_dtype, int fmt, int write, void* stream);
+int mi355_fp8_update_scale(float* states, int n, int stride_floats, int fmt, int margin, void* stream);
+int mi355_pack_weights_fp8(const float* w, void* wf, void* wt, float* state, int O, int T, int I, int margin, void* stream);
+/* mi355_conv_fwd / mi355_conv_dgrad with fp8 operands (d->dtype = MI355_FP8; channels contracted over: a multiple of 128):
+ *   y  (bf16) = (conv(x8, w8)  * *descale_x  * *descale_w + bias) [+ residual]
+ *   dx (bf16) = (dgrad(dy8, wT8) * *descale_dy * *descale_w) * (*scale_dev, optional) [+ dx when accumulate]
+ * partial / nslices (nullable): BatchNorm statistics of the result from the epilogue, as mi355_conv_fwd_stats. */
+int mi355_conv_fwd_fp8(const mi355_conv_desc* d, const void* x8, int x_fmt, const void* w8, const float* descale_x,
+                       const float* descale_w, const float* bias, const void* residual, void* y, float* partial,
+                       size_t partial_bytes, int* nslices, void* stream);
+int mi355_conv_dgrad_fp8(const mi355_conv_desc* d, const void* dy8, int dy_fmt, const void* wT8, const float* descale_dy,
+                         const float* descale_w, const float* scale_dev, int accumulate, void* dx, float* partial,
+                         size_t partial_bytes, int* nslices, void* stream);
 size_t mi355_conv_wgrad_workspace(const mi355_conv_desc* d);
 int mi355_conv_wgrad(const mi355_conv_desc* d, const void* x, const void* dy, float* dw, int accumulate,
                      void* ws, size_t ws_bytes, void* stream);
