@@ -90,13 +90,8 @@ def build_datasets(args):
         mk = lambda n, seed: SyntheticHand21(n, image_size, heatmap_size, seed=seed)
         n = args.batch_size * max(args.iters_per_epoch, 1)
         return mk(n, 11), mk(4 * args.batch_size, 12), mk(n, 13), mk(4 * args.batch_size, 14)
-    try:
-        import uda.dataset as datasets               # the reference's CPU dataset layer, if the user supplies it
-        import uda.dataset.keypoint_detection as T
-    except ImportError as e:
-        raise SystemExit('The CPU dataset / augmentation layer (uda.dataset, PIL+cv2+torchvision) is out of scope of '
-                         'this build: run with --synthetic, or put the reference\'s uda/dataset package on PYTHONPATH '
-                         '(%s)' % e)
+    import uda.dataset as datasets                   # RHD / H3D / STB readers + key-point aware augmentation (PIL + numpy)
+    import uda.dataset.keypoint_detection as T
     normalize = T.Normalize([0.485, 0.456, 0.406], [0.229, 0.224, 0.225])
     train_tf = T.Compose([T.RandomRotation(args.rotation), T.RandomResizedCrop(size=args.image_size, scale=args.resize_scale),
                           T.ColorJitter(brightness=0.25, contrast=0.25, saturation=0.25), T.GaussianBlur(), T.ToTensor(), normalize])

@@ -353,9 +353,34 @@ def g9_generate_target():
     save('g9_generate_target', **out)
 
 
+
+def g10_dataset_util():
+    """Geometry helpers of the data layer run on the reference (uda/dataset/util.py:72-143; cv2 stubbed, import only)."""
+    _stub('cv2')
+    _stub('uda.dataset', f'{REF}/uda/dataset')
+    import uda.dataset.util as ref_util
+    rng = np.random.default_rng(1001)
+    boxes = rng.uniform(-40, 360, size=(200, 4))
+    boxes[:, 2] = boxes[:, 0] + np.abs(rng.normal(60, 50, 200)); boxes[:, 3] = boxes[:, 1] + np.abs(rng.normal(60, 50, 200))
+    dims = rng.integers(100, 700, size=(200, 2))
+    scales = rng.choice([1.0, 1.5, 1.6, 2.0], size=200)
+    scaled = np.array([ref_util.scale_box(tuple(b), int(w), int(h), float(s)) for b, (w, h), s in zip(boxes, dims, scales)], dtype=np.float64)
+    kp = rng.uniform(0, 320, size=(10, 21, 2))
+    Kmat = np.array([[283.1, 0, 160.0], [0, 283.1, 160.0], [0, 0, 1.0]])
+    Zc = rng.uniform(0.3, 1.2, size=(10, 21))
+    xyz = np.stack([ref_util.keypoint2d_to_3d(kp[i], Kmat, Zc[i]) for i in range(10)])
+    uv = np.stack([ref_util.keypoint3d_to_2d(xyz[i], Kmat) for i in range(10)])
+    bbox = np.array([ref_util.get_bounding_box(kp[i]) for i in range(10)])
+    ia = boxes[:100].round(); ib = boxes[100:].round()
+    inter = np.array([ref_util.intersection(tuple(a), tuple(b)) for a, b in zip(ia, ib)])
+    areas = np.array([ref_util.area(*t) for t in inter])
+    save('g10_dataset_util', boxes=boxes, dims=dims, scales=scales, scaled=scaled, kp=kp, K=Kmat, Zc=Zc, xyz=xyz, uv=uv, bbox=bbox,
+         inter=inter, areas=areas)
+
+
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['g1', 'g2', 'g3', 'g4', 'g5', 'g6', 'g7', 'g8', 'g9']
+    which = sys.argv[1:] or ['g1', 'g2', 'g3', 'g4', 'g5', 'g6', 'g7', 'g8', 'g9', 'g10']
     fns = {'g1': g1_neck_heads, 'g2': g2_losses, 'g3': g3_pseudo_labels, 'g4': g4_argmax_accuracy,
-           'g5': g5_softargmax, 'g6': g6_gl, 'g7': g7_iteration, 'g8': g8_bottleneck, 'g9': g9_generate_target}
+           'g5': g5_softargmax, 'g6': g6_gl, 'g7': g7_iteration, 'g8': g8_bottleneck, 'g9': g9_generate_target, 'g10': g10_dataset_util}
     for w in which:
         fns[w]()
