@@ -49,6 +49,7 @@ def parse():
     ap.add_argument('--graph', action='store_true', help='replay HIP graphs also with more than one rank (default there: eager; '
                     'at B=64 the iteration is GPU-bound either way: 44.72 ms replayed vs 44.75 ms eager)')
     ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--no-eval', action='store_true', help='skip the forward-only (test.py path) section: profiler runs that should see training iterations only')
     ap.add_argument('--cpu-baseline-batch', type=int, default=4)
     ap.add_argument('--cpu-baseline-iters', type=int, default=3)
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -205,20 +206,22 @@ def main():
     losses = {k: float(step.out[k]) for k in ('loss_s', 'loss_gf', 'loss_gt')}
 
     # ---- forward-only throughput of the test.py path (eval-mode BatchNorm, main head only, arg-max decode), SURVEY 8(d)
-    model.eval()
-    from utils.keypoint_detection import get_max_preds_device
-    with torch.no_grad():
-        for _ in range(3):
-            get_max_preds_device(model(batch['x_t']))
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        n_eval = 10
-        for _ in range(n_eval):
-            get_max_preds_device(model(batch['x_t']))
-        torch.cuda.synchronize()
-        eval_ms = (time.perf_counter() - t0) / n_eval * 1e3
-    model.train()
-    log('eval path: %.2f ms per batch of %d' % (eval_ms, B))
+    eval_ms = None
+    if not args.no_eval:
+        model.eval()
+        from utils.keypoint_detection import get_max_preds_device
+        with torch.no_grad():
+            for _ in range(3):
+                get_max_preds_device(model(batch['x_t']))
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            n_eval = 10
+            for _ in range(n_eval):
+                get_max_preds_device(model(batch['x_t']))
+            torch.cuda.synchronize()
+            eval_ms = (time.perf_counter() - t0) / n_eval * 1e3
+        model.train()
+        log('eval path: %.2f ms per batch of %d' % (eval_ms, B))
 
     # ---- roofline of the dominant kernel family (MFMA implicit-GEMM conv: gather + wgrad kernels), rank 0:
     # the same K steps again, eagerly, every conv launch bracketed by hipEvents on its stream.
@@ -287,7 +290,7 @@ def main():
                        'arch': args.arch, 'image_size': S, 'per_gpu_batch': B, 'global_batch': B * world,
                        'parallelism': 'dp%d' % world, 'hip_graphs': use_graph},
             'model_passes_per_s': round(3 * B * world / (ms_per_step * 1e-3), 2),
-            'eval_images_per_s_per_gpu': round(B / (eval_ms * 1e-3), 1),
+            'eval_images_per_s_per_gpu': round(B / (eval_ms * 1e-3), 1) if eval_ms else None,
             'losses_last_step': losses,
         }
         if F is not None:

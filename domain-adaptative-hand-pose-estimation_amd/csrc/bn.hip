@@ -189,12 +189,14 @@ template <typename T, bool EVAL>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, const T* __restrict__ res, T* __restrict__ y,
                                                         const float* __restrict__ scale_shift, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, const float* __restrict__ rm,
-                                                        const float* __restrict__ rv, float eps, long rows, int C, int TX, int relu) {
+                                                        const float* __restrict__ rv, float eps, long rows, int C, int TX, int relu,
+                                                        unsigned char* __restrict__ mask) {
   constexpr int CH = Chunk<T>::N;
   const int TY = 256 / TX;
   const int tx = threadIdx.x % TX, ty = threadIdx.x / TX;
   const int chunk = blockIdx.x * TX + tx;
   if (chunk * CH >= C) return;
+  const int cpr = C / CH;
   float sc[CH], sh[CH];
 #pragma unroll
   for (int e = 0; e < CH; ++e) {
@@ -210,6 +212,12 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, 
     if (res) { float w[CH]; Chunk<T>::load(res + off, w);
 #pragma unroll
       for (int e = 0; e < CH; ++e) v[e] += w[e]; }
+    if (mask) {           // one bit per element: y > 0, what the backward's ReLU mask needs instead of re-reading y
+      unsigned m = 0;
+#pragma unroll
+      for (int e = 0; e < CH; ++e) m |= (v[e] > 0.f ? 1u : 0u) << e;
+      mask[(size_t)r * cpr + chunk] = (unsigned char)m;
+    }
     if (relu) {
 #pragma unroll
       for (int e = 0; e < CH; ++e) v[e] = v[e] < 0.f ? 0.f : v[e]; }   // keeps NaN, like ATen relu
@@ -223,9 +231,11 @@ template <typename T, bool XHAT>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict__ dy, const T* __restrict__ x, const T* __restrict__ y,
                                                              const float* __restrict__ mean, const float* __restrict__ invstd,
                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                             float* __restrict__ partial, long rows, int C, int TX, int rows_per_slice, int relu) {
+                                                             float* __restrict__ partial, long rows, int C, int TX, int rows_per_slice, int relu,
+                                                             const unsigned char* __restrict__ mask) {
   constexpr int CH = Chunk<T>::N;
   __shared__ float sh[256 * CH * 2];
+  const int cpr = C / CH;
   const int TY = 256 / TX;
   const int tx = threadIdx.x % TX, ty = threadIdx.x / TX;
   const int chunk = blockIdx.x * TX + tx;
@@ -243,10 +253,13 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
       for (int e = 0; e < CH; ++e) { sc[e] = gamma[chunk * CH + e] * is[e]; sft[e] = beta[chunk * CH + e] - mu[e] * sc[e]; }
     }
   }
-  auto fold = [&](float (&g)[CH], const float (&v)[CH], const float (&o)[CH]) {
+  auto fold = [&](float (&g)[CH], const float (&v)[CH], const float (&o)[CH], unsigned mb) {
     if (relu == 1) {
 #pragma unroll
       for (int e = 0; e < CH; ++e) g[e] = o[e] > 0.f ? g[e] : 0.f; }
+    else if (relu == 3) {
+#pragma unroll
+      for (int e = 0; e < CH; ++e) g[e] = ((mb >> e) & 1u) ? g[e] : 0.f; }
     if (XHAT) {
       if (relu == 2) {
 #pragma unroll
@@ -266,14 +279,16 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
       Chunk<T>::load(dy + off0, g0); Chunk<T>::load(dy + off1, g1);
       if (XHAT) { Chunk<T>::load(x + off0, v0); Chunk<T>::load(x + off1, v1); }
       if (relu == 1) { Chunk<T>::load(y + off0, o0); Chunk<T>::load(y + off1, o1); }
-      fold(g0, v0, o0); fold(g1, v1, o1);
+      unsigned m0 = 0, m1 = 0;
+      if (relu == 3) { m0 = mask[(size_t)r * cpr + chunk]; m1 = mask[(size_t)(r + TY) * cpr + chunk]; }
+      fold(g0, v0, o0, m0); fold(g1, v1, o1, m1);
     }
     if (r < r1) {
       const size_t off = (size_t)r * C + (size_t)chunk * CH;
       float g[CH], v[CH], o[CH]; Chunk<T>::load(dy + off, g);
       if (XHAT) Chunk<T>::load(x + off, v);
       if (relu == 1) Chunk<T>::load(y + off, o);
-      fold(g, v, o);
+      fold(g, v, o, relu == 3 ? (unsigned)mask[(size_t)r * cpr + chunk] : 0u);
     }
   }
 #pragma unroll
@@ -325,12 +340,13 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
                                                             const float* __restrict__ mean, const float* __restrict__ invstd,
                                                             const float* __restrict__ coeff, const float* __restrict__ beta,
                                                             T* __restrict__ dx, T* __restrict__ dres,
-                                                            long rows, int C, int TX, int relu) {
+                                                            long rows, int C, int TX, int relu, const unsigned char* __restrict__ mask) {
   constexpr int CH = Chunk<T>::N;
   const int TY = 256 / TX;
   const int tx = threadIdx.x % TX, ty = threadIdx.x / TX;
   const int chunk = blockIdx.x * TX + tx;
   if (chunk * CH >= C) return;
+  const int cpr = C / CH;
   float k0[CH], k1[CH], k2[CH], mu[CH], is[CH], sh[CH];
 #pragma unroll
   for (int e = 0; e < CH; ++e) {
@@ -338,10 +354,13 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
     k0[e] = coeff[c]; k1[e] = coeff[C + c]; k2[e] = coeff[2 * C + c]; mu[e] = mean[c]; is[e] = invstd[c];
     sh[e] = (relu == 2) ? beta[c] - mu[e] * k0[e] : 0.f;      // k0 = gamma*invstd = forward scale
   }
-  auto finish = [&](size_t off, float (&g)[CH], float (&v)[CH], const float (&o)[CH]) {
+  auto finish = [&](size_t off, float (&g)[CH], float (&v)[CH], const float (&o)[CH], unsigned mb) {
     if (relu == 1) {
 #pragma unroll
       for (int e = 0; e < CH; ++e) g[e] = o[e] > 0.f ? g[e] : 0.f; }
+    else if (relu == 3) {
+#pragma unroll
+      for (int e = 0; e < CH; ++e) g[e] = ((mb >> e) & 1u) ? g[e] : 0.f; }
     else if (relu == 2) {
 #pragma unroll
       for (int e = 0; e < CH; ++e) g[e] = (v[e] * k0[e] + sh[e]) > 0.f ? g[e] : 0.f; }
@@ -359,13 +378,15 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
     Chunk<T>::load(dy + off0, g0); Chunk<T>::load(x + off0, v0);
     Chunk<T>::load(dy + off1, g1); Chunk<T>::load(x + off1, v1);
     if (relu == 1) { Chunk<T>::load(y + off0, o0); Chunk<T>::load(y + off1, o1); }
-    finish(off0, g0, v0, o0); finish(off1, g1, v1, o1);
+    unsigned m0 = 0, m1 = 0;
+    if (relu == 3) { m0 = mask[(size_t)r * cpr + chunk]; m1 = mask[(size_t)(r + stride) * cpr + chunk]; }
+    finish(off0, g0, v0, o0, m0); finish(off1, g1, v1, o1, m1);
   }
   if (r < rows) {
     const size_t off = (size_t)r * C + (size_t)chunk * CH;
     float g[CH], v[CH], o[CH]; Chunk<T>::load(dy + off, g); Chunk<T>::load(x + off, v);
     if (relu == 1) Chunk<T>::load(y + off, o);
-    finish(off, g, v, o);
+    finish(off, g, v, o, relu == 3 ? (unsigned)mask[(size_t)r * cpr + chunk] : 0u);
   }
 }
 
@@ -405,8 +426,9 @@ static dim3 apply_grid(const BnPlan& p, long rows, bool backward = false) {
 extern "C" int mi355_bn_train_fwd(const void* x, const void* residual, void* y, const float* gamma, const float* beta,
                                   float* running_mean, float* running_var, int64_t* nbt, float* save_mean, float* save_invstd,
                                   long rows, int C, float eps, float momentum, int stat_updates, int relu, int dtype, void* ws,
-                                  size_t ws_bytes, void* stream) {
+                                  size_t ws_bytes, void* relu_mask, void* stream) {
   int CH; if (int e = bn_check(rows, C, dtype, &CH)) return e;
+  unsigned char* mk = reinterpret_cast<unsigned char*>(relu_mask);
   if (stat_updates < 0 || stat_updates > 8) MI_FAIL(MI355_EINVAL, "bn_train_fwd: stat_updates=%d", stat_updates);
   if (!ws || ws_bytes < mi355_bn_workspace(rows, C)) MI_FAIL(MI355_EWORKSPACE, "bn_train_fwd: workspace too small");
   hipStream_t st = as_stream(stream);
@@ -419,8 +441,8 @@ extern "C" int mi355_bn_train_fwd(const void* x, const void* residual, void* y, 
   hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 4)), dim3(256), 0, st, partial, p.nslices, C, gamma, beta, running_mean, running_var, nbt, save_mean, save_invstd, ss, eps, momentum, stat_updates);
   dim3 ga = apply_grid(p, rows);
   const float* nf = nullptr;
-  if (dtype == MI355_BF16) hipLaunchKernelGGL((bn_apply_kernel<bf16_t, false>), ga, dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)residual, (bf16_t*)y, (const float*)ss, nf, nf, nf, nf, eps, rows, C, p.TX, relu);
-  else hipLaunchKernelGGL((bn_apply_kernel<float, false>), ga, dim3(256), 0, st, (const float*)x, (const float*)residual, (float*)y, (const float*)ss, nf, nf, nf, nf, eps, rows, C, p.TX, relu);
+  if (dtype == MI355_BF16) hipLaunchKernelGGL((bn_apply_kernel<bf16_t, false>), ga, dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)residual, (bf16_t*)y, (const float*)ss, nf, nf, nf, nf, eps, rows, C, p.TX, relu, mk);
+  else hipLaunchKernelGGL((bn_apply_kernel<float, false>), ga, dim3(256), 0, st, (const float*)x, (const float*)residual, (float*)y, (const float*)ss, nf, nf, nf, nf, eps, rows, C, p.TX, relu, mk);
   MI_CHECK_LAUNCH("bn_train_fwd");
   return MI355_OK;
 }
@@ -431,8 +453,9 @@ extern "C" int mi355_bn_train_fwd_partials(const void* x, const void* residual, 
                                            float* running_mean, float* running_var, int64_t* nbt, float* save_mean,
                                            float* save_invstd, long rows, int C, float eps, float momentum, int stat_updates,
                                            int relu, int dtype, const float* partial, int nslices, float* scale_shift,
-                                           void* stream) {
+                                           void* relu_mask, void* stream) {
   int CH; if (int e = bn_check(rows, C, dtype, &CH)) return e;
+  unsigned char* mk = reinterpret_cast<unsigned char*>(relu_mask);
   if (stat_updates < 0 || stat_updates > 8) MI_FAIL(MI355_EINVAL, "bn_train_fwd_partials: stat_updates=%d", stat_updates);
   if (!partial || nslices < 1 || !scale_shift) MI_FAIL(MI355_EINVAL, "bn_train_fwd_partials: partial / scale_shift missing");
   hipStream_t st = as_stream(stream);
@@ -442,8 +465,8 @@ extern "C" int mi355_bn_train_fwd_partials(const void* x, const void* residual, 
   else hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 4)), dim3(256), 0, st, partial, nslices, C, gamma, beta, running_mean, running_var, nbt, save_mean, save_invstd, scale_shift, eps, momentum, stat_updates);
   dim3 ga = apply_grid(p, rows);
   const float* nf = nullptr;
-  if (dtype == MI355_BF16) hipLaunchKernelGGL((bn_apply_kernel<bf16_t, false>), ga, dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)residual, (bf16_t*)y, (const float*)scale_shift, nf, nf, nf, nf, eps, rows, C, p.TX, relu);
-  else hipLaunchKernelGGL((bn_apply_kernel<float, false>), ga, dim3(256), 0, st, (const float*)x, (const float*)residual, (float*)y, (const float*)scale_shift, nf, nf, nf, nf, eps, rows, C, p.TX, relu);
+  if (dtype == MI355_BF16) hipLaunchKernelGGL((bn_apply_kernel<bf16_t, false>), ga, dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)residual, (bf16_t*)y, (const float*)scale_shift, nf, nf, nf, nf, eps, rows, C, p.TX, relu, mk);
+  else hipLaunchKernelGGL((bn_apply_kernel<float, false>), ga, dim3(256), 0, st, (const float*)x, (const float*)residual, (float*)y, (const float*)scale_shift, nf, nf, nf, nf, eps, rows, C, p.TX, relu, mk);
   MI_CHECK_LAUNCH("bn_train_fwd_partials");
   return MI355_OK;
 }
@@ -456,32 +479,33 @@ extern "C" int mi355_bn_eval_fwd(const void* x, const void* residual, void* y, c
   BnPlan p = bn_plan(rows, C, CH);
   dim3 ga = apply_grid(p, rows);
   const float* nf = nullptr;
-  if (dtype == MI355_BF16) hipLaunchKernelGGL((bn_apply_kernel<bf16_t, true>), ga, dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)residual, (bf16_t*)y, nf, gamma, beta, running_mean, running_var, eps, rows, C, p.TX, relu);
-  else hipLaunchKernelGGL((bn_apply_kernel<float, true>), ga, dim3(256), 0, st, (const float*)x, (const float*)residual, (float*)y, nf, gamma, beta, running_mean, running_var, eps, rows, C, p.TX, relu);
+  if (dtype == MI355_BF16) hipLaunchKernelGGL((bn_apply_kernel<bf16_t, true>), ga, dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)residual, (bf16_t*)y, nf, gamma, beta, running_mean, running_var, eps, rows, C, p.TX, relu, (unsigned char*)nullptr);
+  else hipLaunchKernelGGL((bn_apply_kernel<float, true>), ga, dim3(256), 0, st, (const float*)x, (const float*)residual, (float*)y, nf, gamma, beta, running_mean, running_var, eps, rows, C, p.TX, relu, (unsigned char*)nullptr);
   MI_CHECK_LAUNCH("bn_eval_fwd");
   return MI355_OK;
 }
 
 extern "C" int mi355_bn_bwd(const void* dy, const void* x, const void* y, const float* gamma, const float* beta, const float* save_mean,
                             const float* save_invstd, void* dx, void* dresidual, float* dgamma, float* dbeta, int accumulate,
-                            long rows, int C, int relu, int dtype, void* ws, size_t ws_bytes, void* stream) {
+                            long rows, int C, int relu, int dtype, void* ws, size_t ws_bytes, const void* relu_mask, void* stream) {
   int CH; if (int e = bn_check(rows, C, dtype, &CH)) return e;
   if (!ws || ws_bytes < mi355_bn_workspace(rows, C)) MI_FAIL(MI355_EWORKSPACE, "bn_bwd: workspace too small");
-  // relu: the mask comes from y when it is given; without y it is recomputed from x (only valid when the forward had
-  // no residual add), which saves one tensor read in each of the two passes
-  if (relu) relu = y ? 1 : 2;
+  // relu: the mask comes from the bit mask the forward wrote (1 bit / element), else from y when it is given; without
+  // either it is recomputed from x (only valid when the forward had no residual add): one tensor read less per pass
+  const unsigned char* mk = reinterpret_cast<const unsigned char*>(relu_mask);
+  if (relu) relu = mk ? 3 : (y ? 1 : 2);
   if (relu == 2 && !beta) MI_FAIL(MI355_EINVAL, "bn_bwd: relu without y needs beta");
   hipStream_t st = as_stream(stream);
   BnPlan p = bn_plan(rows, C, CH, bwd_slices());
   float* partial = reinterpret_cast<float*>(ws);
   float* coeff = partial + (size_t)p.nslices * C * 3;   // 3*C floats (4*C reserved)
   dim3 g(p.colgroups, p.nslices);
-  if (dtype == MI355_BF16) hipLaunchKernelGGL((bn_bwd_reduce_kernel<bf16_t, true>), g, dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)x, (const bf16_t*)y, save_mean, save_invstd, gamma, beta, partial, rows, C, p.TX, p.rows_per_slice, relu);
-  else hipLaunchKernelGGL((bn_bwd_reduce_kernel<float, true>), g, dim3(256), 0, st, (const float*)dy, (const float*)x, (const float*)y, save_mean, save_invstd, gamma, beta, partial, rows, C, p.TX, p.rows_per_slice, relu);
+  if (dtype == MI355_BF16) hipLaunchKernelGGL((bn_bwd_reduce_kernel<bf16_t, true>), g, dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)x, (const bf16_t*)y, save_mean, save_invstd, gamma, beta, partial, rows, C, p.TX, p.rows_per_slice, relu, mk);
+  else hipLaunchKernelGGL((bn_bwd_reduce_kernel<float, true>), g, dim3(256), 0, st, (const float*)dy, (const float*)x, (const float*)y, save_mean, save_invstd, gamma, beta, partial, rows, C, p.TX, p.rows_per_slice, relu, mk);
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 4)), dim3(256), 0, st, partial, p.nslices, C, 1.0f / (float)rows, gamma, save_invstd, dgamma, dbeta, accumulate, coeff);
   dim3 ga = apply_grid(p, rows, true);
-  if (dtype == MI355_BF16) hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, ga, dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)x, (const bf16_t*)y, save_mean, save_invstd, coeff, beta, (bf16_t*)dx, (bf16_t*)dresidual, rows, C, p.TX, relu);
-  else hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, ga, dim3(256), 0, st, (const float*)dy, (const float*)x, (const float*)y, save_mean, save_invstd, coeff, beta, (float*)dx, (float*)dresidual, rows, C, p.TX, relu);
+  if (dtype == MI355_BF16) hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, ga, dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)x, (const bf16_t*)y, save_mean, save_invstd, coeff, beta, (bf16_t*)dx, (bf16_t*)dresidual, rows, C, p.TX, relu, mk);
+  else hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, ga, dim3(256), 0, st, (const float*)dy, (const float*)x, (const float*)y, save_mean, save_invstd, coeff, beta, (float*)dx, (float*)dresidual, rows, C, p.TX, relu, mk);
   MI_CHECK_LAUNCH("bn_bwd");
   return MI355_OK;
 }
@@ -491,17 +515,18 @@ extern "C" int mi355_bn_bwd(const void* dy, const void* x, const void* y, const 
 extern "C" int mi355_bn_bwd_partials(const void* dy, const void* x, const void* y, const float* gamma, const float* beta,
                                      const float* save_mean, const float* save_invstd, void* dx, void* dresidual, float* dgamma,
                                      float* dbeta, int accumulate, long rows, int C, int relu, int dtype, const float* partial,
-                                     int nslices, float* coeff, void* stream) {
+                                     int nslices, float* coeff, const void* relu_mask, void* stream) {
   int CH; if (int e = bn_check(rows, C, dtype, &CH)) return e;
   if (!partial || nslices < 1 || !coeff) MI_FAIL(MI355_EINVAL, "bn_bwd_partials: partial / coeff missing");
-  if (relu) relu = y ? 1 : 2;
+  const unsigned char* mk = reinterpret_cast<const unsigned char*>(relu_mask);
+  if (relu) relu = mk ? 3 : (y ? 1 : 2);
   if (relu == 2 && !beta) MI_FAIL(MI355_EINVAL, "bn_bwd_partials: relu without y needs beta");
   hipStream_t st = as_stream(stream);
   BnPlan p = bn_plan(rows, C, CH);
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 4)), dim3(256), 0, st, partial, nslices, C, 1.0f / (float)rows, gamma, save_invstd, dgamma, dbeta, accumulate, coeff);
   dim3 ga = apply_grid(p, rows, true);
-  if (dtype == MI355_BF16) hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, ga, dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)x, (const bf16_t*)y, save_mean, save_invstd, coeff, beta, (bf16_t*)dx, (bf16_t*)dresidual, rows, C, p.TX, relu);
-  else hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, ga, dim3(256), 0, st, (const float*)dy, (const float*)x, (const float*)y, save_mean, save_invstd, coeff, beta, (float*)dx, (float*)dresidual, rows, C, p.TX, relu);
+  if (dtype == MI355_BF16) hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, ga, dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)x, (const bf16_t*)y, save_mean, save_invstd, coeff, beta, (bf16_t*)dx, (bf16_t*)dresidual, rows, C, p.TX, relu, mk);
+  else hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, ga, dim3(256), 0, st, (const float*)dy, (const float*)x, (const float*)y, save_mean, save_invstd, coeff, beta, (float*)dx, (float*)dresidual, rows, C, p.TX, relu, mk);
   MI_CHECK_LAUNCH("bn_bwd_partials");
   return MI355_OK;
 }
@@ -514,8 +539,8 @@ extern "C" int mi355_colsum(const void* dy, float* out, long rows, int C, int dt
   BnPlan p = bn_plan(rows, C, CH);
   float* partial = reinterpret_cast<float*>(ws);
   dim3 g(p.colgroups, p.nslices);
-  if (dtype == MI355_BF16) hipLaunchKernelGGL((bn_bwd_reduce_kernel<bf16_t, false>), g, dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)nullptr, (const bf16_t*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, partial, rows, C, p.TX, p.rows_per_slice, 0);
-  else hipLaunchKernelGGL((bn_bwd_reduce_kernel<float, false>), g, dim3(256), 0, st, (const float*)dy, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, partial, rows, C, p.TX, p.rows_per_slice, 0);
+  if (dtype == MI355_BF16) hipLaunchKernelGGL((bn_bwd_reduce_kernel<bf16_t, false>), g, dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)nullptr, (const bf16_t*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, partial, rows, C, p.TX, p.rows_per_slice, 0, (const unsigned char*)nullptr);
+  else hipLaunchKernelGGL((bn_bwd_reduce_kernel<float, false>), g, dim3(256), 0, st, (const float*)dy, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, partial, rows, C, p.TX, p.rows_per_slice, 0, (const unsigned char*)nullptr);
   hipLaunchKernelGGL(colsum_finalize_kernel, dim3(cdiv(C, 4)), dim3(256), 0, st, partial, p.nslices, C, out, accumulate);
   MI_CHECK_LAUNCH("colsum");
   return MI355_OK;

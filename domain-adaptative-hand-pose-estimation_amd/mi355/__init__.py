@@ -57,11 +57,11 @@ SIGNATURES = {
     'mi355_colsum_workspace': (_Z, [_L, _I]),
     'mi355_colsum': (_I, [_P, _P, _L, _I, _I, _I, _P, _Z, _P]),
     'mi355_bn_workspace': (_Z, [_L, _I]),
-    'mi355_bn_train_fwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _F, _F, _I, _I, _I, _P, _Z, _P]),
-    'mi355_bn_train_fwd_partials': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _F, _F, _I, _I, _I, _P, _I, _P, _P]),
+    'mi355_bn_train_fwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _F, _F, _I, _I, _I, _P, _Z, _P, _P]),
+    'mi355_bn_train_fwd_partials': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _F, _F, _I, _I, _I, _P, _I, _P, _P, _P]),
     'mi355_bn_eval_fwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _L, _I, _F, _I, _I, _P]),
-    'mi355_bn_bwd_partials': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _L, _I, _I, _I, _P, _I, _P, _P]),
-    'mi355_bn_bwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _L, _I, _I, _I, _P, _Z, _P]),
+    'mi355_bn_bwd_partials': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _L, _I, _I, _I, _P, _I, _P, _P, _P]),
+    'mi355_bn_bwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _L, _I, _I, _I, _P, _Z, _P, _P]),
     'mi355_maxpool_fwd': (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
     'mi355_maxpool_bwd': (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
     'mi355_nchw_to_nhwc': (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
@@ -283,8 +283,31 @@ class on_side:
         return self.ctx.__exit__(*exc)
 
 
+# MI355_WGRAD_DEFER=1 (experiment): weight gradients are not launched where autograd reaches them but collected and issued
+# in batches on the side stream -- one fork per batch (at the stage boundaries of the backward, DAStep._on_stage_grad)
+# instead of one per layer -- so that they run beside the dgrad / BatchNorm-backward chain of the next stage.
+DEFER_WGRAD = _os.environ.get('MI355_WGRAD_DEFER', '0') == '1'
+_deferred = []
+
+
+def defer_wgrad(fn, keep):
+    _deferred.append((fn, keep))
+
+
+def flush_wgrads(device=None):
+    """Issue the collected weight-gradient launches on the side stream (ordered after everything enqueued so far)."""
+    if not _deferred:
+        return
+    dev = device if device is not None else _deferred[0][1][0].device
+    with on_side(dev, keep=tuple(t for _, keep in _deferred for t in keep)):
+        for fn, _ in _deferred:
+            fn()
+    del _deferred[:]
+
+
 def join_side():
     """Current stream waits for all side-stream work; releases the tensors kept alive for it."""
+    flush_wgrads()
     if _pending:
         for st in _side.values():
             torch.cuda.current_stream().wait_stream(st)

@@ -144,6 +144,8 @@ class DAStep:
             mod.register_forward_hook(fwd_hook(stage))
 
     def _on_stage_grad(self, stage):
+        if _rt.DEFER_WGRAD:
+            _rt.flush_wgrads()           # the weight gradients collected behind this tensor start on the side stream now
         if self._reducer is not None:
             self._reducer.stage_done(stage)
 

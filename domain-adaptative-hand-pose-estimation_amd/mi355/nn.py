@@ -178,6 +178,7 @@ _FUSE_STATS = _os.environ.get('MI355_BN_STATS_FUSE', '1') == '1'      # A/B swit
 _FUSE_BNBWD = _os.environ.get('MI355_BN_BWD_FUSE', '0') == '1'        # opt-in: BN backward reduction in the dgrad epilogue (measured neutral)
 _SKIP_FUSE = _os.environ.get('MI355_SKIP_FUSE', '1') == '1'             # A/B switch: residual-fork gradient add inside dgrad
 _MASK_FROM_Y = _os.environ.get('MI355_BN_MASK_FROM_Y', '0') == '1'     # A/B switch: read y for every ReLU mask
+_RELU_BITMASK = _os.environ.get('MI355_BN_RELU_BITMASK', '1') == '1'   # A/B switch: bit mask instead of y for BN + residual + ReLU
 
 # dy tensors whose producing GEMM already reduced them for the BatchNorm backward: data_ptr -> (dy, (partial, nslices)).
 # The entry keeps dy alive, so its address cannot be reused while the entry exists; BatchNorm's backward pops it.
@@ -360,7 +361,9 @@ class _DeconvFn(torch.autograd.Function):
         dx = None
         if ctx.needs_input_grad[1]:
             g, acc = grad_slot(weight)
-            if _rt.side_wgrad_for(desc):
+            if _rt.DEFER_WGRAD:
+                _rt.defer_wgrad(lambda: ops.conv_wgrad(desc, dy, x, g, acc, ws_tag='side'), (x, dy))
+            elif _rt.side_wgrad_for(desc):
                 with _rt.on_side(x.device, keep=(x, dy)):
                     ops.conv_wgrad(desc, dy, x, g, acc, ws_tag='side')      # conv-form input = dy, conv-form output = x
             else:
@@ -384,12 +387,16 @@ class _DeconvFn(torch.autograd.Function):
 class _BnFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, gamma, beta, residual, mod, relu, partial=None):
+        # The backward's ReLU mask: recomputed from x when no residual was added; with a residual it is (y > 0), kept as a
+        # bit mask the apply pass writes on the side (1/16 of the bytes of y) -- y itself only for the A/B switches
+        keep_y = relu and (_MASK_FROM_Y or (residual is not None and (_FUSE_BNBWD or not _RELU_BITMASK)))
+        mask = ops.bn_relu_mask(x) if (relu and residual is not None and not keep_y and
+                                       (x.requires_grad or gamma.requires_grad)) else None
         y, mean, invstd = ops.bn_train_fwd(x, residual, gamma, beta, mod.running_mean, mod.running_var,
                                            mod.num_batches_tracked, mod.eps, mod.momentum, relu, _rt.bn_stat_updates,
-                                           partial=partial)
+                                           partial=partial, relu_mask=mask)
         ctx.relu = relu
-        # the ReLU mask is recomputed from x in backward unless a residual was added (then it needs y)
-        keep_y = relu and (residual is not None or _MASK_FROM_Y)
+        ctx.mask = mask
         ctx.save_for_backward(x, y if keep_y else None, mean, invstd, gamma, beta)
         mod._last_src = (x, bool(keep_y), gamma, beta, mean, invstd, bool(relu))
         return y
@@ -408,7 +415,7 @@ class _BnFn(torch.autograd.Function):
         ent = _BWD_PARTIALS.pop(dy.data_ptr(), None)       # dy already reduced by the GEMM epilogue that produced it?
         partial = ent[1] if (ent is not None and ent[0].shape == dy.shape and ent[0].dtype == dy.dtype) else None
         dx, dres = ops.bn_bwd(dy, x, y, gamma, mean, invstd, dg, db, acc, ctx.relu, ctx.needs_input_grad[3], beta=beta,
-                              partial=partial)
+                              partial=partial, relu_mask=ctx.mask)
         return (dx if ctx.needs_input_grad[0] else None), None, None, dres, None, None, None
 
 
@@ -625,7 +632,9 @@ class Conv2d(nn.Module):
     def _wgrad(self, desc, x, dy, weight):
         g, acc = grad_slot(weight)
         if desc.Ci == self.in_channels:
-            if _rt.side_wgrad_for(desc):
+            if _rt.DEFER_WGRAD:
+                _rt.defer_wgrad(lambda: ops.conv_wgrad(desc, x, dy, g, acc, ws_tag='side'), (x, dy))
+            elif _rt.side_wgrad_for(desc):
                 with _rt.on_side(x.device, keep=(x, dy)):
                     ops.conv_wgrad(desc, x, dy, g, acc, ws_tag='side')
             else:

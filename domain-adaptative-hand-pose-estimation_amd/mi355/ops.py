@@ -253,9 +253,16 @@ def conv_dgrad_fp8(desc, dy8, dy_state, wT8, w_state, scale_dev=None, out=None, 
 
 
 # ---------------------------------------------------------------- batch norm
+def bn_relu_mask(x):
+    """uint8 buffer for the ReLU bit mask of a BatchNorm over x: one byte per 16-byte chunk of every row."""
+    per = 8 if x.dtype == torch.bfloat16 else 4
+    return torch.empty(x.numel() // per, dtype=torch.uint8, device=x.device)
+
+
 def bn_train_fwd(x, residual, gamma, beta, running_mean, running_var, nbt, eps, momentum, relu, stat_updates=1,
-                 partial=None):
-    """partial: (buffer, nslices) from conv_fwd_stats / conv_dgrad_stats of the conv that produced x -> no statistics pass."""
+                 partial=None, relu_mask=None):
+    """partial: (buffer, nslices) from conv_fwd_stats / conv_dgrad_stats of the conv that produced x -> no statistics pass.
+    relu_mask: bn_relu_mask(x) buffer that receives the (y > 0) bits for the backward (instead of keeping y)."""
     _chk_dev(x, gamma)
     N, C, H, W = x.shape
     rows = N * H * W
@@ -267,12 +274,12 @@ def bn_train_fwd(x, residual, gamma, beta, running_mean, running_var, nbt, eps, 
         ss = torch.empty(2 * C, dtype=torch.float32, device=x.device)
         call('mi355_bn_train_fwd_partials', ptr(x), ptr(residual), ptr(y), ptr(gamma), ptr(beta), ptr(running_mean),
              ptr(running_var), ptr(nbt), ptr(mean), ptr(invstd), rows, C, float(eps), float(momentum), int(stat_updates),
-             int(relu), dtype_code(x.dtype), ptr(buf), int(ns), ptr(ss), stream_ptr())
+             int(relu), dtype_code(x.dtype), ptr(buf), int(ns), ptr(ss), ptr(relu_mask), stream_ptr())
         return y, mean, invstd
     ws = workspace(load().mi355_bn_workspace(rows, C), x.device)
     call('mi355_bn_train_fwd', ptr(x), ptr(residual), ptr(y), ptr(gamma), ptr(beta), ptr(running_mean),
          ptr(running_var), ptr(nbt), ptr(mean), ptr(invstd), rows, C, float(eps), float(momentum), int(stat_updates), int(relu),
-         dtype_code(x.dtype), ptr(ws), ws.numel(), stream_ptr())
+         dtype_code(x.dtype), ptr(ws), ws.numel(), ptr(relu_mask), stream_ptr())
     return y, mean, invstd
 
 
@@ -285,8 +292,9 @@ def bn_eval_fwd(x, residual, gamma, beta, running_mean, running_var, eps, relu):
     return y
 
 
-def bn_bwd(dy, x, y, gamma, mean, invstd, dgamma, dbeta, accumulate, relu, want_dres, beta=None, partial=None):
-    """partial: (buffer, nslices) reduction partials from the GEMM epilogue that produced dy -> no reduction pass."""
+def bn_bwd(dy, x, y, gamma, mean, invstd, dgamma, dbeta, accumulate, relu, want_dres, beta=None, partial=None, relu_mask=None):
+    """partial: (buffer, nslices) reduction partials from the GEMM epilogue that produced dy -> no reduction pass.
+    relu_mask: the bit mask the forward wrote (then y is not needed)."""
     N, C, H, W = x.shape
     rows = N * H * W
     dx = nhwc_empty(N, C, H, W, x.dtype, x.device)
@@ -296,12 +304,12 @@ def bn_bwd(dy, x, y, gamma, mean, invstd, dgamma, dbeta, accumulate, relu, want_
         coeff = torch.empty(3 * C, dtype=torch.float32, device=x.device)
         call('mi355_bn_bwd_partials', ptr(dy), ptr(x), ptr(y), ptr(gamma), ptr(beta), ptr(mean), ptr(invstd), ptr(dx),
              ptr(dres), ptr(dgamma), ptr(dbeta), int(accumulate), rows, C, int(relu), dtype_code(x.dtype), ptr(buf), int(ns),
-             ptr(coeff), stream_ptr())
+             ptr(coeff), ptr(relu_mask), stream_ptr())
         return dx, dres
     ws = workspace(load().mi355_bn_workspace(rows, C), x.device)
     call('mi355_bn_bwd', ptr(dy), ptr(x), ptr(y), ptr(gamma), ptr(beta), ptr(mean), ptr(invstd), ptr(dx), ptr(dres),
          ptr(dgamma), ptr(dbeta), int(accumulate), rows, C, int(relu), dtype_code(x.dtype), ptr(ws), ws.numel(),
-         stream_ptr())
+         ptr(relu_mask), stream_ptr())
     return dx, dres
 
 

@@ -146,30 +146,34 @@ int mi355_colsum(const void* dy, float* out, long rows, int C, int dtype, int ac
  *      dresidual (nullable) = dy_eff ; dgamma/dbeta (=|+=).
  *      With relu and y == NULL the mask is recomputed from x (valid when the forward had no residual): one
  *      tensor read less in each backward pass.
+ * relu_mask (nullable, all four entry points): [rows][C / chunk] bytes, chunk = 8 (bf16) / 4 (fp32) channels, bit e of a
+ *      byte = (y > 0) of channel chunk*chunk_size + e.  The forward writes it; a backward given the mask takes the ReLU
+ *      mask from it and reads neither y nor beta: 1/16 of the bytes of y in each of the two backward passes of a
+ *      BatchNorm + residual + ReLU (the last BatchNorm of every residual block).
  */
 size_t mi355_bn_workspace(long rows, int C);
 int mi355_bn_train_fwd(const void* x, const void* residual, void* y, const float* gamma, const float* beta,
                        float* running_mean, float* running_var, int64_t* num_batches_tracked,
                        float* save_mean, float* save_invstd, long rows, int C, float eps, float momentum,
-                       int stat_updates, int relu, int dtype, void* ws, size_t ws_bytes, void* stream);
+                       int stat_updates, int relu, int dtype, void* ws, size_t ws_bytes, void* relu_mask, void* stream);
 /* mi355_bn_train_fwd without its statistics pass: the partials come from mi355_conv_fwd_stats / _dgrad_stats.
  * scale_shift: 2*C floats of scratch. */
 int mi355_bn_train_fwd_partials(const void* x, const void* residual, void* y, const float* gamma, const float* beta,
                                 float* running_mean, float* running_var, int64_t* num_batches_tracked,
                                 float* save_mean, float* save_invstd, long rows, int C, float eps, float momentum,
                                 int stat_updates, int relu, int dtype, const float* partial, int nslices,
-                                float* scale_shift, void* stream);
+                                float* scale_shift, void* relu_mask, void* stream);
 int mi355_bn_eval_fwd(const void* x, const void* residual, void* y, const float* gamma, const float* beta,
                       const float* running_mean, const float* running_var, long rows, int C, float eps,
                       int relu, int dtype, void* stream);
 int mi355_bn_bwd_partials(const void* dy, const void* x, const void* y, const float* gamma, const float* beta,
                           const float* save_mean, const float* save_invstd, void* dx, void* dresidual, float* dgamma,
                           float* dbeta, int accumulate, long rows, int C, int relu, int dtype, const float* partial,
-                          int nslices, float* coeff, void* stream);
+                          int nslices, float* coeff, const void* relu_mask, void* stream);
 int mi355_bn_bwd(const void* dy, const void* x, const void* y, const float* gamma, const float* beta,
                  const float* save_mean, const float* save_invstd, void* dx, void* dresidual, float* dgamma, float* dbeta,
                  int accumulate, long rows, int C, int relu, int dtype, void* ws, size_t ws_bytes,
-                 void* stream);
+                 const void* relu_mask, void* stream);
 
 /* ---------------------------------------------------------------- stem max-pool 3x3 s2 p1
  * Replaces nn.MaxPool2d(3,2,1) of the torchvision stem (uda/model/resnet.py:28).  argidx: uint8 window

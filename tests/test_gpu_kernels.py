@@ -212,6 +212,18 @@ def test_bn_train_fwd_bwd(gpu, dt, shape, relu, res):
         assert float((_back(dres) - rr.grad).abs().max()) <= _tol(dt, rr.grad)
     assert float((dg.cpu() - gr.grad).abs().max()) <= 2e-3 * (float(gr.grad.abs().max()) + 1) * (8 if dt == 'bf16' else 1)
     assert float((db.cpu() - br.grad).abs().max()) <= 2e-3 * (float(br.grad.abs().max()) + 1) * (8 if dt == 'bf16' else 1)
+    if relu and res:
+        # the bit mask written by the forward's apply pass replaces y in the backward: same results, bit for bit
+        mask = ops.bn_relu_mask(xd)
+        y2, _, _ = ops.bn_train_fwd(xd, rd, gamma.to(gpu), beta.to(gpu), rm.to(gpu), rv.to(gpu), nbt.clone(), 1e-5, 0.1, relu, relu_mask=mask)
+        assert torch.equal(y2, y)
+        per = 8 if dt == 'bf16' else 4
+        bits = (mask.view(N * H * W, C // per, 1) >> torch.arange(per, device=gpu).view(1, 1, per)) & 1
+        assert torch.equal(bits.view(N, H, W, C).permute(0, 3, 1, 2).bool(), y > 0)
+        dg2 = torch.zeros(C, device=gpu); db2 = torch.zeros(C, device=gpu)
+        dx2, dres2 = ops.bn_bwd(_nhwc(dy, dt, gpu), xd, None, gamma.to(gpu), mean, invstd, dg2, db2, False, relu, res,
+                                beta=beta.to(gpu), relu_mask=mask)
+        assert torch.equal(dx2, dx) and torch.equal(dres2, dres) and torch.equal(dg2, dg) and torch.equal(db2, db)
     # eval mode
     ye = ops.bn_eval_fwd(xd, rd, gamma.to(gpu), beta.to(gpu), rm.to(gpu), rv.to(gpu), 1e-5, relu)
     ye_ref = F.batch_norm(x, rm, rv, gamma, beta, False, 0.1, 1e-5)
