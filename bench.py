@@ -77,16 +77,19 @@ def host_cores():
     return max(1, min(n, 64))
 
 
-def pmc_traffic(args):
-    """HBM bytes per launch of the conv family measured offline with rocprofv3 PMC passes on this same command
-    (profiles/r01_pmc_traffic.json: corrected as MI355X_MICROARCH.md prescribes, FETCH_SIZE doubled); null for
-    configurations that were not profiled."""
+def pmc_record(args):
+    """Counter evidence collected offline on this same workload (profiles/collect_pmc.sh -> profiles/r02_pmc_traffic.json:
+    rocprofv3 kernel trace + separate --pmc FETCH_SIZE / WRITE_SIZE passes, folded per kernel family by
+    profiles/pmc_fold.py with the gfx950 correction of MI355X_MICROARCH.md).  Returns the record of this configuration
+    (or None) and the name + git commit of the file, so that a stale file is visible in the JSON line."""
+    path = os.path.join(ROOT, 'profiles', 'r02_pmc_traffic.json')
     try:
-        rec = json.load(open(os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')))
+        rec = json.load(open(path))
         key = '%s_%d_b%d_%s' % (args.arch, args.image_size, args.batch_size, args.dtype)
-        return rec['configs'][key]['conv_family_bytes_per_launch']
+        cfg = rec['configs'][key]
+        return cfg, {'file': 'profiles/r02_pmc_traffic.json', 'collected_at_commit': cfg.get('git_head'), 'command': cfg.get('command')}
     except Exception:
-        return None
+        return None, None
 
 
 def cpu_baseline(arch, image_size, batch, iters):
@@ -256,7 +259,7 @@ def main():
         peak = PEAK_TFLOPS[args.dtype]
         roof = {'bound': 'mfma', 'kernel': 'gather_gemm_kernel%s + wgrad_gemm_kernel + wgrad_kw_kernel (implicit-GEMM conv family)' % (' + gather_fp8_kernel' if args.dtype == 'fp8' else ''),
                 'achieved': round(ach, 2), 'peak': peak, 'unit': 'TFLOP/s', 'frac': round(ach / peak, 4),
-                'traffic': pmc_traffic(args), 'traffic_unit': 'bytes per launch (rocprofv3 PMC: 2*FETCH_SIZE + WRITE_SIZE, separate passes)',
+                'traffic': None, 'traffic_unit': 'bytes per launch (rocprofv3 PMC: 2*FETCH_SIZE + WRITE_SIZE, separate passes)',
                 'algorithmic_bytes_per_launch': round(abytes / launches), 'launches_per_step': launches // n_prof,
                 'algorithmic_gflop_per_launch': round(algo / launches / 1e9, 3),
                 'avg_launch_us': round(ms * 1e3 / launches, 2),
@@ -298,6 +301,19 @@ def main():
             res['iteration_tflops_per_gpu_algorithmic_9BF'] = round(tf, 2)
             res['iteration_frac_of_mfma_peak'] = round(tf / PEAK_TFLOPS[args.dtype], 4)
         if roof is not None:
+            cfg, src = pmc_record(args)
+            if cfg is not None:
+                fam = cfg['families']
+                roof['traffic'] = cfg.get('conv_family_bytes_per_launch')
+                roof['traffic_source'] = src
+                # counter-based HBM rates of the memory-bound stages (north star: "achieved HBM GB/s on the BN / soft-argmax
+                # stages"): measured bytes / measured kernel time per family, with the algorithmic bytes beside them
+                roof['membound'] = {k: {kk: v[kk] for kk in ('launches', 'bytes_per_launch', 'counter_GBps', 'frac_of_8TBps',
+                                                             'algorithmic_bytes_per_launch', 'traffic_over_algorithmic') if kk in v}
+                                    for k, v in fam.items() if k in ('bn_fwd', 'bn_bwd', 'kl_loss', 'argmax', 'softargmax',
+                                                                     'pseudo_label', 'slab_reduce', 'pointwise21', 'optimizer')}
+                if 'conv_mfma' in fam and 'traffic_over_algorithmic' in fam['conv_mfma']:
+                    roof['traffic_over_algorithmic'] = fam['conv_mfma']['traffic_over_algorithmic']
             res['roofline'] = roof
         if not args.no_cpu_baseline:
             res['cpu_baseline'] = cpu_baseline(args.arch, S, args.cpu_baseline_batch, args.cpu_baseline_iters)

@@ -227,12 +227,15 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, 
 
 // -------------------------------------------------------------------------------- backward
 // partial[slice][c] = (sum dy_eff, sum dy_eff * xhat)
-template <typename T, bool XHAT>
+// RELU (compile time, so that every variant carries only the registers it needs: the bf16 apply kernel sits right at the
+// 128-VGPR occupancy step): 0 none, 1 mask from y > 0, 2 mask recomputed from x, 3 mask from the forward's bit mask
+template <typename T, bool XHAT, int RELU>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict__ dy, const T* __restrict__ x, const T* __restrict__ y,
                                                              const float* __restrict__ mean, const float* __restrict__ invstd,
                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                             float* __restrict__ partial, long rows, int C, int TX, int rows_per_slice, int relu,
+                                                             float* __restrict__ partial, long rows, int C, int TX, int rows_per_slice,
                                                              const unsigned char* __restrict__ mask) {
+  constexpr int relu = RELU;
   constexpr int CH = Chunk<T>::N;
   __shared__ float sh[256 * CH * 2];
   const int cpr = C / CH;
@@ -335,13 +338,14 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
   if (coeff) { coeff[c] = g * is; coeff[C + c] = s1 * inv_rows; coeff[2 * C + c] = s2 * inv_rows; }
 }
 
-template <typename T>
+template <typename T, int RELU>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ dy, const T* __restrict__ x, const T* __restrict__ y,
                                                             const float* __restrict__ mean, const float* __restrict__ invstd,
                                                             const float* __restrict__ coeff, const float* __restrict__ beta,
                                                             T* __restrict__ dx, T* __restrict__ dres,
-                                                            long rows, int C, int TX, int relu, const unsigned char* __restrict__ mask) {
+                                                            long rows, int C, int TX, const unsigned char* __restrict__ mask) {
   constexpr int CH = Chunk<T>::N;
+  constexpr int relu = RELU;
   const int TY = 256 / TX;
   const int tx = threadIdx.x % TX, ty = threadIdx.x / TX;
   const int chunk = blockIdx.x * TX + tx;
@@ -485,6 +489,16 @@ extern "C" int mi355_bn_eval_fwd(const void* x, const void* residual, void* y, c
   return MI355_OK;
 }
 
+static void launch_bwd_apply(int dtype, int relu, dim3 ga, hipStream_t st, const void* dy, const void* x, const void* y, const float* save_mean,
+                             const float* save_invstd, const float* coeff, const float* beta, void* dx, void* dresidual, long rows, int C,
+                             int TX, const unsigned char* mk) {
+#define MI_APP(T, R) hipLaunchKernelGGL((bn_bwd_apply_kernel<T, R>), ga, dim3(256), 0, st, (const T*)dy, (const T*)x, (const T*)y, save_mean, save_invstd, coeff, beta, (T*)dx, (T*)dresidual, rows, C, TX, mk)
+#define MI_APP4(T) do { if (relu == 0) MI_APP(T, 0); else if (relu == 1) MI_APP(T, 1); else if (relu == 2) MI_APP(T, 2); else MI_APP(T, 3); } while (0)
+  if (dtype == MI355_BF16) MI_APP4(bf16_t); else MI_APP4(float);
+#undef MI_APP4
+#undef MI_APP
+}
+
 extern "C" int mi355_bn_bwd(const void* dy, const void* x, const void* y, const float* gamma, const float* beta, const float* save_mean,
                             const float* save_invstd, void* dx, void* dresidual, float* dgamma, float* dbeta, int accumulate,
                             long rows, int C, int relu, int dtype, void* ws, size_t ws_bytes, const void* relu_mask, void* stream) {
@@ -500,12 +514,14 @@ extern "C" int mi355_bn_bwd(const void* dy, const void* x, const void* y, const 
   float* partial = reinterpret_cast<float*>(ws);
   float* coeff = partial + (size_t)p.nslices * C * 3;   // 3*C floats (4*C reserved)
   dim3 g(p.colgroups, p.nslices);
-  if (dtype == MI355_BF16) hipLaunchKernelGGL((bn_bwd_reduce_kernel<bf16_t, true>), g, dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)x, (const bf16_t*)y, save_mean, save_invstd, gamma, beta, partial, rows, C, p.TX, p.rows_per_slice, relu, mk);
-  else hipLaunchKernelGGL((bn_bwd_reduce_kernel<float, true>), g, dim3(256), 0, st, (const float*)dy, (const float*)x, (const float*)y, save_mean, save_invstd, gamma, beta, partial, rows, C, p.TX, p.rows_per_slice, relu, mk);
+#define MI_RED(T, R) hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, true, R>), g, dim3(256), 0, st, (const T*)dy, (const T*)x, (const T*)y, save_mean, save_invstd, gamma, beta, partial, rows, C, p.TX, p.rows_per_slice, mk)
+#define MI_RED4(T) do { if (relu == 0) MI_RED(T, 0); else if (relu == 1) MI_RED(T, 1); else if (relu == 2) MI_RED(T, 2); else MI_RED(T, 3); } while (0)
+  if (dtype == MI355_BF16) MI_RED4(bf16_t); else MI_RED4(float);
+#undef MI_RED4
+#undef MI_RED
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 4)), dim3(256), 0, st, partial, p.nslices, C, 1.0f / (float)rows, gamma, save_invstd, dgamma, dbeta, accumulate, coeff);
   dim3 ga = apply_grid(p, rows, true);
-  if (dtype == MI355_BF16) hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, ga, dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)x, (const bf16_t*)y, save_mean, save_invstd, coeff, beta, (bf16_t*)dx, (bf16_t*)dresidual, rows, C, p.TX, relu, mk);
-  else hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, ga, dim3(256), 0, st, (const float*)dy, (const float*)x, (const float*)y, save_mean, save_invstd, coeff, beta, (float*)dx, (float*)dresidual, rows, C, p.TX, relu, mk);
+  launch_bwd_apply(dtype, relu, ga, st, dy, x, y, save_mean, save_invstd, coeff, beta, dx, dresidual, rows, C, p.TX, mk);
   MI_CHECK_LAUNCH("bn_bwd");
   return MI355_OK;
 }
@@ -525,8 +541,7 @@ extern "C" int mi355_bn_bwd_partials(const void* dy, const void* x, const void* 
   BnPlan p = bn_plan(rows, C, CH);
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 4)), dim3(256), 0, st, partial, nslices, C, 1.0f / (float)rows, gamma, save_invstd, dgamma, dbeta, accumulate, coeff);
   dim3 ga = apply_grid(p, rows, true);
-  if (dtype == MI355_BF16) hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, ga, dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)x, (const bf16_t*)y, save_mean, save_invstd, coeff, beta, (bf16_t*)dx, (bf16_t*)dresidual, rows, C, p.TX, relu, mk);
-  else hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, ga, dim3(256), 0, st, (const float*)dy, (const float*)x, (const float*)y, save_mean, save_invstd, coeff, beta, (float*)dx, (float*)dresidual, rows, C, p.TX, relu, mk);
+  launch_bwd_apply(dtype, relu, ga, st, dy, x, y, save_mean, save_invstd, coeff, beta, dx, dresidual, rows, C, p.TX, mk);
   MI_CHECK_LAUNCH("bn_bwd_partials");
   return MI355_OK;
 }
@@ -539,8 +554,8 @@ extern "C" int mi355_colsum(const void* dy, float* out, long rows, int C, int dt
   BnPlan p = bn_plan(rows, C, CH);
   float* partial = reinterpret_cast<float*>(ws);
   dim3 g(p.colgroups, p.nslices);
-  if (dtype == MI355_BF16) hipLaunchKernelGGL((bn_bwd_reduce_kernel<bf16_t, false>), g, dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)nullptr, (const bf16_t*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, partial, rows, C, p.TX, p.rows_per_slice, 0, (const unsigned char*)nullptr);
-  else hipLaunchKernelGGL((bn_bwd_reduce_kernel<float, false>), g, dim3(256), 0, st, (const float*)dy, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, partial, rows, C, p.TX, p.rows_per_slice, 0, (const unsigned char*)nullptr);
+  if (dtype == MI355_BF16) hipLaunchKernelGGL((bn_bwd_reduce_kernel<bf16_t, false, 0>), g, dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)nullptr, (const bf16_t*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, partial, rows, C, p.TX, p.rows_per_slice, (const unsigned char*)nullptr);
+  else hipLaunchKernelGGL((bn_bwd_reduce_kernel<float, false, 0>), g, dim3(256), 0, st, (const float*)dy, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, partial, rows, C, p.TX, p.rows_per_slice, (const unsigned char*)nullptr);
   hipLaunchKernelGGL(colsum_finalize_kernel, dim3(cdiv(C, 4)), dim3(256), 0, st, partial, p.nslices, C, out, accumulate);
   MI_CHECK_LAUNCH("colsum");
   return MI355_OK;

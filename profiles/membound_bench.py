@@ -11,10 +11,16 @@ from mi355 import ops
 dev = torch.device('cuda:0'); mi355.load(); dt = torch.bfloat16
 
 
+import os
+EAGER = os.environ.get('MEMBOUND_EAGER') == '1'      # under rocprofv3 --pmc: plain launches, no graphs, counters per kernel
+
+
 def timeit(fn, n=50):
     for _ in range(5):
         fn()
     torch.cuda.synchronize()
+    if EAGER:
+        return float('nan')
     g = torch.cuda.CUDAGraph()
     with torch.cuda.graph(g):
         for _ in range(n):
