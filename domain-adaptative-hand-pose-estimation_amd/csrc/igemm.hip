@@ -1166,7 +1166,9 @@ static int dispatch_gather(GatherArgs& a, hipStream_t st) {
     // 256x128 macro tile (128 accumulators per wave, 2 blocks/CU, 0.21 KB of L1 traffic per MFMA): 313 -> 302 us on the 64x64 layers
     else if (kw3 && t128 >= 4096 && kw3_on != 2 && kw3_on != 4) { if constexpr (sizeof(T) == 2) launch_gather<T, 256, 128, false, 2, 2, false, false, true>(a, st); }
     else if (kw3 && (t128 >= 2048 || kw3_on == 2)) { if constexpr (sizeof(T) == 2) launch_gather<T, 128, 128, false, 2, 2, false, false, true>(a, st); }
-    else if ((dma_mode == 2 && a.Nout > 64) || (dma_mode == 1 && t128 >= 512 && kavg >= 128)) launch_gather<T, 128, 128, false, 2, 2, false, true>(a, st);
+    // (also the K-heavy mid-size layers, 256 .. 511 tiles with K >= 2048: 3x3 256->256 @16x16 36.2 -> 32.7 us; a 3-stage ring with
+    //  two tiles in flight and counted vmcnt measured 33.5 us there: the per-CU fill rate, not latency, bounds these layers)
+    else if ((dma_mode == 2 && a.Nout > 64) || (dma_mode == 1 && ((t128 >= 512 && kavg >= 128) || (t128 >= 256 && kavg >= 256)))) launch_gather<T, 128, 128, false, 2, 2, false, true>(a, st);
     // short-K 1x1 convs at large M are all prologue / epilogue and HBM-bound: more, smaller blocks in flight win
     // (64->256 @64x64: 54.5 -> 47.0 us, 256->256: 79.6 -> 68.9 us)
     else if (t128 >= 512 && kavg <= 32 && sizeof(T) == 2) launch_gather<T, 64, 128, false>(a, st);
