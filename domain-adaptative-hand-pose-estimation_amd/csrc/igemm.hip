@@ -540,14 +540,18 @@ struct WgradArgs {
 // tr16-read friendly swizzle of a [rows][256 B] bf16 image (guide T10, image (b))
 __device__ __forceinline__ int swz256(int r, int ch) { return r * 256 + ((ch ^ (((r & 3) << 2) | ((r >> 2) & 3))) << 4); }
 
+template <typename T> struct WgradSmem {
+  static constexpr int BKM = (sizeof(T) == 2) ? 64 : 32;
+  static constexpr int kBytes = 2 * BKM * 128 * (int)sizeof(T) + 2 * BKM * 8;
+};
+// body shared by the single-problem kernel and the grouped one (`bid` of `nblk` blocks work on problem p)
 template <typename T>
-__global__ __launch_bounds__(256, 3) void wgrad_gemm_kernel(const WgradArgs p) {
+__device__ __forceinline__ void wgrad_gemm_body(const WgradArgs& p, const int bid, const int nblk, char* smem) {
   constexpr int CH = MmaTraits<T>::CH;
   constexpr int BKM = (sizeof(T) == 2) ? 64 : 32;   // reduction rows per LDS tile
   constexpr int CPR = 128 / CH;                      // chunks per 128-wide tile row
   constexpr int RPT = BKM * CPR / 256;               // rows per thread per operand
   constexpr int ROWB = 128 * (int)sizeof(T);         // LDS row bytes
-  __shared__ __attribute__((aligned(16))) char smem[2 * BKM * ROWB + 2 * BKM * 8];
   char* ys = smem;                 // DY tile [BKM][128 o]
   char* xs = smem + BKM * ROWB;    // X  tile [BKM][128 cols]
   // pixel decode of the reduction rows, shared by the 16/32 lanes that stage one row: one thread per row decodes
@@ -558,7 +562,7 @@ __global__ __launch_bounds__(256, 3) void wgrad_gemm_kernel(const WgradArgs p) {
   // XCD-aware order: all tiles of one pixel range (split) are neighbours in the remapped id, i.e. share an XCD / L2,
   // so the DY and X rows of that range are fetched into one L2 instead of eight
   const int ntile = p.nto * p.nti;
-  const int lid = xcd_remap(blockIdx.x, gridDim.x);
+  const int lid = xcd_remap(bid, nblk);
   const int split = lid / ntile, tile = lid - split * ntile;
   const int o0 = (tile / p.nti) * 128, c0 = (tile % p.nti) * 128;  // c0: flattened (tap, ci) column
   const int wm0 = (wave >> 1) * 64, wn0 = (wave & 1) * 64;
@@ -691,6 +695,45 @@ __global__ __launch_bounds__(256, 3) void wgrad_gemm_kernel(const WgradArgs p) {
         const int c = c0 + wn0 + j * 32 + r31;
         if (o < p.Co && c < p.ldw) out[(size_t)o * p.ldw + c] = acc[i][j][r];
       }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256, 3) void wgrad_gemm_kernel(const WgradArgs p) {
+  __shared__ __attribute__((aligned(16))) char smem[WgradSmem<T>::kBytes];
+  wgrad_gemm_body<T>(p, blockIdx.x, gridDim.x, smem);
+}
+
+// Several independent weight-gradient problems in ONE launch (the small layers of a ResNet stage: each alone offers
+// 16 .. 64 output tiles, far too few for 256 CUs, so the single-problem launch splits its pixel range 16 .. 48 ways and
+// pays for it with as many fp32 slabs plus a reduce launch).  Grouped, the tiles of all problems fill the chip together:
+// 2 .. 4 splits per problem, long K loops, one launch + one grouped slab reduce for the whole stage.  The argument blocks
+// travel by value in the kernel-argument segment (graph-capturable, no device table).
+#define WG_MAX 24
+struct WgradGroupArgs { WgradArgs p[WG_MAX]; int bstart[WG_MAX + 1]; int n; };
+template <typename T>
+__global__ __launch_bounds__(256, 3) void wgrad_group_kernel(const WgradGroupArgs g) {
+  __shared__ __attribute__((aligned(16))) char smem[WgradSmem<T>::kBytes];
+  int i = 0;
+  while (i + 1 < g.n && (int)blockIdx.x >= g.bstart[i + 1]) ++i;         // block-uniform scan of <= 24 entries
+  wgrad_gemm_body<T>(g.p[i], (int)blockIdx.x - g.bstart[i], g.bstart[i + 1] - g.bstart[i], smem);
+}
+
+// grouped fixed-order slab reduction: out_i (=|+=) sum over the S_i slabs of problem i, one float4 column per thread
+struct SlabItem { const float* slabs; float* out; long n4, stride; int S, accumulate; };
+struct SlabGroupArgs { SlabItem it[WG_MAX]; int bstart[WG_MAX + 1]; int n; };
+__global__ __launch_bounds__(256) void slab_reduce_group_kernel(const SlabGroupArgs g) {
+  int i = 0;
+  while (i + 1 < g.n && (int)blockIdx.x >= g.bstart[i + 1]) ++i;
+  const SlabItem& q = g.it[i];
+  const long c = (long)((int)blockIdx.x - g.bstart[i]) * 256 + threadIdx.x;
+  if (c >= q.n4) return;
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int s = 0; s < q.S; ++s) {
+    const float4 a = reinterpret_cast<const float4*>(q.slabs + (size_t)s * q.stride)[c];
+    v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
+  }
+  if (q.accumulate) { const float4 o = reinterpret_cast<const float4*>(q.out)[c]; v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
+  reinterpret_cast<float4*>(q.out)[c] = v;
 }
 
 // ------------------------------------------------------------------------------------ wgrad, 3x3 stride 1 (bf16)
@@ -1503,6 +1546,121 @@ extern "C" int mi355_conv_wgrad(const mi355_conv_desc* d, const void* x, const v
     launch_slab_reduce(reinterpret_cast<const float*>(ws), dw, n, w.S, a.slab_stride, accumulate, st);
     MI_CHECK_LAUNCH("slab_reduce");
   }
+  return MI355_OK;
+}
+
+
+// ------------------------------------------------------------------------------------ grouped weight gradients
+// items: HOST array.  Problems the specialised kernels take (3x3 stride 1 -> wgrad_kw, 3x3 / 4x4 stride 2 -> wgrad_kw2), and
+// any problem that fills the chip on its own, run through mi355_conv_wgrad one by one; the rest -- the generic kernel's
+// small problems -- are launched in groups of up to WG_MAX with a split count chosen for the GROUP.
+static bool group_eligible(const mi355_conv_desc* d, const WgradPlan& w) {
+  return !w.kw2 && !w.kw3 && (long)w.nto * w.nti < 384;
+}
+struct GroupPlan { int S, rps; size_t ws_off; };
+static long group_plan(const mi355_wgrad_item* items, const int* idx, int n, GroupPlan* gp, size_t* ws_bytes) {
+  // equal work per block: block-steps W = sum tiles_i * ksteps_i; aim at 3 blocks per CU, never fewer than 16 K-steps per block
+  double W = 0;
+  for (int k = 0; k < n; ++k) {
+    const mi355_conv_desc* d = &items[idx[k]].d; WgradPlan w = plan_wgrad(d);
+    const int bkm = d->dtype == MI355_BF16 ? 64 : 32;
+    W += (double)w.nto * w.nti * (((long)d->N * d->Ho * d->Wo + bkm - 1) / bkm);
+  }
+  static const int group_blocks = getenv("MI355_WG_GROUP_BLOCKS") ? atoi(getenv("MI355_WG_GROUP_BLOCKS")) : 768;
+  long per = (long)(W / group_blocks) + 1; if (per < 16) per = 16;
+  long blocks = 0; size_t off = 0;
+  for (int k = 0; k < n; ++k) {
+    const mi355_wgrad_item& it = items[idx[k]]; const mi355_conv_desc* d = &it.d; WgradPlan w = plan_wgrad(d);
+    const int bkm = d->dtype == MI355_BF16 ? 64 : 32;
+    const long M = (long)d->N * d->Ho * d->Wo, ksteps = (M + bkm - 1) / bkm;
+    long S = (ksteps + per - 1) / per; if (S < 1) S = 1;
+    long rps = (M + S - 1) / S; rps = ((rps + bkm - 1) / bkm) * bkm;
+    S = (M + rps - 1) / rps;
+    gp[k].S = (int)S; gp[k].rps = (int)rps; gp[k].ws_off = off;
+    if (S > 1 || it.accumulate) off += (size_t)S * d->Co * w.ldw * sizeof(float);
+    blocks += (long)w.nto * w.nti * S;
+  }
+  if (ws_bytes) *ws_bytes = off;
+  return blocks;
+}
+extern "C" size_t mi355_conv_wgrad_grouped_workspace(const mi355_wgrad_item* items, int n) {
+  if (!items || n < 1) return 0;
+  size_t need = 0;
+  int idx[WG_MAX]; int m = 0; GroupPlan gp[WG_MAX];
+  for (int i = 0; i <= n; ++i) {
+    bool flush = (i == n) || m == WG_MAX;
+    if (i < n) {
+      WgradPlan w = plan_wgrad(&items[i].d);
+      if (!group_eligible(&items[i].d, w)) { size_t b = mi355_conv_wgrad_workspace(&items[i].d); if (b > need) need = b; continue; }
+      if (m && items[idx[0]].d.dtype != items[i].d.dtype) flush = true;
+    }
+    if (flush && m) { size_t b = 0; group_plan(items, idx, m, gp, &b); if (b > need) need = b; m = 0; }
+    if (i < n && group_eligible(&items[i].d, plan_wgrad(&items[i].d))) idx[m++] = i;
+  }
+  if (m) { size_t b = 0; group_plan(items, idx, m, gp, &b); if (b > need) need = b; }
+  return need;
+}
+static int launch_wgrad_group(const mi355_wgrad_item* items, const int* idx, int n, void* ws, size_t ws_bytes, hipStream_t st) {
+  GroupPlan gp[WG_MAX]; size_t need = 0;
+  group_plan(items, idx, n, gp, &need);
+  if (need && (!ws || ws_bytes < need)) MI_FAIL(MI355_EWORKSPACE, "wgrad group workspace %zu < %zu", ws_bytes, need);
+  WgradGroupArgs g; memset(&g, 0, sizeof(g));
+  SlabGroupArgs sg; memset(&sg, 0, sizeof(sg));
+  int nb = 0, nsb = 0;
+  for (int k = 0; k < n; ++k) {
+    const mi355_wgrad_item& it = items[idx[k]]; const mi355_conv_desc* d = &it.d;
+    if (int e = check_desc(d)) return e;
+    const int CH = d->dtype == MI355_BF16 ? 8 : 4;
+    if (d->Ci % CH || d->Co % CH) MI_FAIL(MI355_EINVAL, "wgrad: channels must be multiples of %d", CH);
+    const int cshift = ilog2_exact(d->Ci / CH);
+    if (cshift < 0) MI_FAIL(MI355_EINVAL, "wgrad: Ci/%d must be a power of two", CH);
+    WgradPlan w = plan_wgrad(d);
+    const bool direct = gp[k].S == 1 && !it.accumulate;
+    WgradArgs& a = g.p[k];
+    a.X = it.x; a.DY = it.dy; a.out = direct ? it.dw : reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + gp[k].ws_off);
+    a.Hi = d->Hi; a.Wi = d->Wi; a.Ci = d->Ci; a.Ho = d->Ho; a.Wo = d->Wo; a.Co = d->Co;
+    a.kw = d->kw; a.stride = d->stride; a.pad = d->pad; a.cshift = cshift;
+    a.M = d->N * d->Ho * d->Wo; a.rows_per_split = gp[k].rps; a.ldw = w.ldw;
+    a.slab_stride = (long)d->Co * w.ldw; a.nto = w.nto; a.nti = w.nti;
+    a.dWo = make_fastdiv(d->Wo); a.dHo = make_fastdiv(d->Ho);
+    const long esz = d->dtype == MI355_BF16 ? 2 : 4;
+    a.x_bytes = (unsigned)((long)d->N * d->Hi * d->Wi * d->Ci * esz); a.dy_bytes = (unsigned)((long)a.M * d->Co * esz);
+    g.bstart[k] = nb; nb += w.nto * w.nti * gp[k].S;
+    if (!direct) {
+      SlabItem& q = sg.it[sg.n];
+      q.slabs = a.out; q.out = it.dw; q.n4 = a.slab_stride / 4; q.stride = a.slab_stride; q.S = gp[k].S; q.accumulate = it.accumulate;
+      sg.bstart[sg.n] = nsb; nsb += cdiv(q.n4, 256); ++sg.n;
+    }
+  }
+  g.bstart[n] = nb; g.n = n; sg.bstart[sg.n] = nsb;
+  {
+    double flops = 0, bytes = 0;
+    for (int k = 0; k < n; ++k) { const WgradArgs& a = g.p[k]; flops += 2.0 * a.M * (double)a.Co * a.ldw; bytes += (double)a.x_bytes + a.dy_bytes + 4.0 * a.Co * a.ldw; }
+    ProfScope ps(st, flops, bytes);
+    if (items[idx[0]].d.dtype == MI355_BF16) hipLaunchKernelGGL(wgrad_group_kernel<bf16_t>, dim3(nb), dim3(256), 0, st, g);
+    else hipLaunchKernelGGL(wgrad_group_kernel<float>, dim3(nb), dim3(256), 0, st, g);
+    MI_CHECK_LAUNCH("wgrad_group");
+  }
+  if (sg.n) { hipLaunchKernelGGL(slab_reduce_group_kernel, dim3(nsb), dim3(256), 0, st, sg); MI_CHECK_LAUNCH("slab_reduce_group"); }
+  return MI355_OK;
+}
+extern "C" int mi355_conv_wgrad_grouped(const mi355_wgrad_item* items, int n, void* ws, size_t ws_bytes, void* stream) {
+  if (!items || n < 1) MI_FAIL(MI355_EINVAL, "wgrad_grouped: no items");
+  hipStream_t st = as_stream(stream);
+  int idx[WG_MAX]; int m = 0;
+  for (int i = 0; i < n; ++i) {
+    const mi355_wgrad_item& it = items[i];
+    if (int e = check_desc(&it.d)) return e;
+    if (!it.x || !it.dy || !it.dw) MI_FAIL(MI355_EINVAL, "wgrad_grouped: item %d has a null operand", i);
+    WgradPlan w = plan_wgrad(&it.d);
+    if (!group_eligible(&it.d, w)) {
+      if (int e = mi355_conv_wgrad(&it.d, it.x, it.dy, it.dw, it.accumulate, ws, ws_bytes, stream)) return e;
+      continue;
+    }
+    if (m && (m == WG_MAX || items[idx[0]].d.dtype != it.d.dtype)) { if (int e = launch_wgrad_group(items, idx, m, ws, ws_bytes, st)) return e; m = 0; }
+    idx[m++] = i;
+  }
+  if (m) { if (int e = launch_wgrad_group(items, idx, m, ws, ws_bytes, st)) return e; }
   return MI355_OK;
 }
 

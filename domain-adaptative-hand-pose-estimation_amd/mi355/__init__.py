@@ -26,6 +26,12 @@ class ConvDesc(ctypes.Structure):
                 ('N', 'Hi', 'Wi', 'Ci', 'Ho', 'Wo', 'Co', 'kh', 'kw', 'stride', 'pad', 'dtype')]
 
 
+class WgradItem(ctypes.Structure):
+    """mi355_wgrad_item: one problem of mi355_conv_wgrad_grouped."""
+    _fields_ = [('d', ConvDesc), ('x', ctypes.c_void_p), ('dy', ctypes.c_void_p), ('dw', ctypes.c_void_p),
+                ('accumulate', ctypes.c_int), ('pad_', ctypes.c_int)]
+
+
 class BnBwdSrc(ctypes.Structure):
     """mi355_bn_bwd_src: saved forward state of the BatchNorm whose dy a GEMM epilogue reduces."""
     _fields_ = [('x', ctypes.c_void_p), ('y', ctypes.c_void_p), ('gamma', ctypes.c_void_p), ('beta', ctypes.c_void_p),
@@ -52,6 +58,8 @@ SIGNATURES = {
     'mi355_conv_dgrad_fp8': (_I, [_D, _P, _I, _P, _P, _P, _P, _I, _P, _P, _Z, _P, _P]),
     'mi355_conv_wgrad_workspace': (_Z, [_D]),
     'mi355_conv_wgrad': (_I, [_D, _P, _P, _P, _I, _P, _Z, _P]),
+    'mi355_conv_wgrad_grouped_workspace': (_Z, [_P, _I]),
+    'mi355_conv_wgrad_grouped': (_I, [_P, _I, _P, _Z, _P]),
     'mi355_pack_weights': (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
     'mi355_pack_weights_batched': (_I, [_P, _I, _I, _I, _P]),
     'mi355_colsum_workspace': (_Z, [_L, _I]),
@@ -305,8 +313,52 @@ def flush_wgrads(device=None):
     del _deferred[:]
 
 
+# ---------------------------------------------------------------- grouped weight gradients
+# Inside `with grouped_wgrads():` (the training step wraps each forward+backward in it) the conv layers do not launch their
+# weight gradients where autograd reaches them; the problems are collected and handed to mi355_conv_wgrad_grouped in batches
+# -- at the stage boundaries of the backward (DAStep._on_stage_grad) and when the block ends -- so that the many small
+# layers of a ResNet stage share one launch.  Outside such a block every weight gradient is launched immediately
+# (a caller may read param.grad right after backward()).
+GROUP_WGRAD = _os.environ.get('MI355_WGRAD_GROUP', '1') == '1'
+_group_depth = 0
+_group_items = []
+
+
+class grouped_wgrads:
+    def __enter__(self):
+        global _group_depth
+        _group_depth += 1
+
+    def __exit__(self, *exc):
+        global _group_depth
+        _group_depth -= 1
+        if _group_depth == 0:
+            if exc[0] is None:
+                flush_grouped_wgrads()
+            else:
+                del _group_items[:]
+
+
+def grouping_wgrads():
+    return GROUP_WGRAD and _group_depth > 0
+
+
+def group_wgrad(desc, x, dy, dw, accumulate):
+    _group_items.append((desc, x, dy, dw, bool(accumulate)))
+
+
+def flush_grouped_wgrads():
+    if not _group_items:
+        return
+    from . import ops
+    items = list(_group_items)
+    del _group_items[:]
+    ops.conv_wgrad_grouped(items)
+
+
 def join_side():
     """Current stream waits for all side-stream work; releases the tensors kept alive for it."""
+    flush_grouped_wgrads()
     flush_wgrads()
     if _pending:
         for st in _side.values():

@@ -144,6 +144,7 @@ class DAStep:
             mod.register_forward_hook(fwd_hook(stage))
 
     def _on_stage_grad(self, stage):
+        _rt.flush_grouped_wgrads()       # the weight gradients of the stage just finished: one grouped launch
         if _rt.DEFER_WGRAD:
             _rt.flush_wgrads()           # the weight gradients collected behind this tensor start on the side stream now
         if self._reducer is not None:
@@ -166,12 +167,13 @@ class DAStep:
         m, c = self.model, self.crit
         for o in self.opt.values():
             o.zero_grad()
-        y_s, y_s_adv, y_s_adv2, y_s_adv3, _ = m(b['x_s'])
-        loss_s = 2 * c['kl'](y_s, b['label_s'], b['w_s']) + \
-            4 * c['rd2'](y_s, y_s_adv2, None, b['w_s'], mode='min') + \
-            4 * c['rd'](y_s, y_s_adv, None, b['w_s'], mode='min') + \
-            4 * c['rd1'](y_s, y_s_adv3, b['w_s'], mode='min')
-        loss_s.backward()
+        with _rt.grouped_wgrads():
+            y_s, y_s_adv, y_s_adv2, y_s_adv3, _ = m(b['x_s'])
+            loss_s = 2 * c['kl'](y_s, b['label_s'], b['w_s']) + \
+                4 * c['rd2'](y_s, y_s_adv2, None, b['w_s'], mode='min') + \
+                4 * c['rd'](y_s, y_s_adv, None, b['w_s'], mode='min') + \
+                4 * c['rd1'](y_s, y_s_adv3, b['w_s'], mode='min')
+            loss_s.backward()
         _rt.join_side()
         self.out.update(loss_s=loss_s.detach(), y_s=y_s.detach(), y_s_adv=y_s_adv.detach())
 
@@ -199,7 +201,8 @@ class DAStep:
         loss2 = to * c['rd'](y_t, y_t_adv, target5, b['w_t'], mode='max')
         loss3 = to * c['rd2'](y_t, y_t_adv2, target0, b['w_t'], mode='max')
         loss_gf = 0.3 * loss1 + 1 * loss2 + 0.3 * loss3
-        loss_gf.backward()
+        with _rt.grouped_wgrads():
+            loss_gf.backward()
         _rt.join_side()
         self.out.update(loss_gf=loss_gf.detach())
 
@@ -223,7 +226,8 @@ class DAStep:
             loss1 = to * c['rd2'](y_t, y_t_adv2, None, b['w_t'], mode='min')
             loss2 = to * c['rd'](y_t, y_t_adv, None, b['w_t'], mode='min')
             loss_gt = 0.3 * loss1 + 1 * loss2
-            loss_gt.backward()
+            with _rt.grouped_wgrads():
+                loss_gt.backward()
             _rt.join_side()
         finally:
             if self.skip:

@@ -361,7 +361,9 @@ class _DeconvFn(torch.autograd.Function):
         dx = None
         if ctx.needs_input_grad[1]:
             g, acc = grad_slot(weight)
-            if _rt.DEFER_WGRAD:
+            if _rt.grouping_wgrads():
+                _rt.group_wgrad(desc, dy, x, g, acc)
+            elif _rt.DEFER_WGRAD:
                 _rt.defer_wgrad(lambda: ops.conv_wgrad(desc, dy, x, g, acc, ws_tag='side'), (x, dy))
             elif _rt.side_wgrad_for(desc):
                 with _rt.on_side(x.device, keep=(x, dy)):
@@ -632,7 +634,9 @@ class Conv2d(nn.Module):
     def _wgrad(self, desc, x, dy, weight):
         g, acc = grad_slot(weight)
         if desc.Ci == self.in_channels:
-            if _rt.DEFER_WGRAD:
+            if _rt.grouping_wgrads():
+                _rt.group_wgrad(desc, x, dy, g, acc)
+            elif _rt.DEFER_WGRAD:
                 _rt.defer_wgrad(lambda: ops.conv_wgrad(desc, x, dy, g, acc, ws_tag='side'), (x, dy))
             elif _rt.side_wgrad_for(desc):
                 with _rt.on_side(x.device, keep=(x, dy)):

@@ -8,7 +8,7 @@ import ctypes
 
 import torch
 
-from . import (BnBwdSrc, ConvDesc, FP8, Mi355Error, call, compute_dtype, dtype_code, load, ptr, stream_ptr, workspace)
+from . import (BnBwdSrc, ConvDesc, FP8, Mi355Error, WgradItem, call, compute_dtype, dtype_code, load, ptr, stream_ptr, workspace)
 
 
 # ---------------------------------------------------------------- layout helpers
@@ -140,6 +140,19 @@ def conv_wgrad(desc, x, dy, dw, accumulate, ws_tag='main'):
     ws = workspace(need, x.device, ws_tag)
     call('mi355_conv_wgrad', ctypes.byref(desc), ptr(x), ptr(dy), ptr(dw), int(accumulate), ptr(ws), ws.numel(),
          stream_ptr())
+
+
+def conv_wgrad_grouped(items, ws_tag='main'):
+    """items: list of (desc, x, dy, dw, accumulate) as for conv_wgrad.  One C call: small problems share launches."""
+    n = len(items)
+    arr = (WgradItem * n)()
+    for i, (desc, x, dy, dw, acc) in enumerate(items):
+        _chk_dev(x, dy, dw)
+        arr[i].d = desc
+        arr[i].x, arr[i].dy, arr[i].dw, arr[i].accumulate = ptr(x), ptr(dy), ptr(dw), int(acc)
+    need = load().mi355_conv_wgrad_grouped_workspace(arr, n)
+    ws = workspace(need, items[0][1].device, ws_tag)
+    call('mi355_conv_wgrad_grouped', arr, n, ptr(ws), ws.numel(), stream_ptr())
 
 
 def pack_weights(w_master, O, T, I, Ipad, dtype, want_f=True, want_t=True):

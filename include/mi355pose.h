@@ -121,6 +121,14 @@ int mi355_conv_dgrad_fp8(const mi355_conv_desc* d, const void* dy8, int dy_fmt, 
 size_t mi355_conv_wgrad_workspace(const mi355_conv_desc* d);
 int mi355_conv_wgrad(const mi355_conv_desc* d, const void* x, const void* dy, float* dw, int accumulate,
                      void* ws, size_t ws_bytes, void* stream);
+/* Many weight gradients in one call (the layers of one ResNet stage, collected during its backward pass).  Small problems --
+ * each offers too few output tiles to fill 256 CUs, so mi355_conv_wgrad splits its pixel range 16..48 ways into fp32 slabs -- are
+ * launched TOGETHER (up to 24 per launch, split counts chosen for the group, one grouped slab reduction); problems that have a
+ * specialised kernel or fill the chip alone go through mi355_conv_wgrad unchanged.  items: HOST array; results as mi355_conv_wgrad.
+ * NOTE: the non-grouped problems reuse `ws` one after the other (stream order), the grouped ones get disjoint regions. */
+typedef struct mi355_wgrad_item { mi355_conv_desc d; const void* x; const void* dy; float* dw; int accumulate; int pad_; } mi355_wgrad_item;
+size_t mi355_conv_wgrad_grouped_workspace(const mi355_wgrad_item* items, int n);
+int mi355_conv_wgrad_grouped(const mi355_wgrad_item* items, int n, void* ws, size_t ws_bytes, void* stream);
 /* fp32 master [O][T][I] -> packed `dtype` copies: wf [O][T][Ipad] (cast) and/or wt [Ipad][T][O] (transposed);
  * channels I..Ipad-1 are zero (the 3-channel stem is padded to one 16-byte chunk). */
 int mi355_pack_weights(const float* w, void* wf, void* wt, int O, int T, int I, int Ipad, int dtype, void* stream);

@@ -604,3 +604,31 @@ def test_pointwise_k2c_epilogue_bn_statistics(gpu, dt, shape):
     assert torch.allclose(ma, mb, rtol=1e-5, atol=1e-6) and torch.allclose(ia, ib, rtol=2e-5, atol=1e-6)
     assert torch.allclose(rma, rmb, rtol=1e-5, atol=1e-6) and torch.allclose(rva, rvb, rtol=2e-5, atol=1e-6)
     assert float((ya.float() - yb.float()).abs().max()) <= (2e-2 if dt == 'bf16' else 1e-4)
+
+
+@pytest.mark.parametrize('dt', ['f32', 'bf16'])
+def test_grouped_weight_gradients_match_single_launches(gpu, dt):
+    """mi355_conv_wgrad_grouped: many small problems in one launch (split counts chosen for the group, grouped slab
+    reduction) against mi355_conv_wgrad problem by problem -- same sums up to the fp32 summation order -- including
+    accumulate=1, a strided 1x1, a 3x3 that goes to the specialised kernel, and more problems than one group holds."""
+    ops = _ops()
+    tdt = torch.float32 if dt == 'f32' else torch.bfloat16
+    shapes = [(4, 16, 16, 64, 256, 1, 1, 0), (4, 16, 16, 256, 64, 1, 1, 0), (2, 8, 8, 512, 128, 1, 1, 0), (4, 16, 16, 64, 128, 1, 2, 0),
+              (2, 16, 16, 64, 64, 3, 1, 1), (3, 8, 8, 128, 512, 1, 1, 0), (2, 16, 16, 32, 64, 3, 2, 1)] * 4          # 28 problems
+    items, refs = [], []
+    for i, (N, H, W, Ci, Co, k, s, p) in enumerate(shapes):
+        d = ops.make_desc(N, H, W, Ci, Co, k, k, s, p, tdt)
+        x = ops.nhwc_empty(N, Ci, H, W, tdt, gpu).copy_(randn(100 + i, N, Ci, H, W).to(gpu))
+        dy = ops.nhwc_empty(N, Co, d.Ho, d.Wo, tdt, gpu).copy_(randn(200 + i, N, Co, d.Ho, d.Wo).to(gpu))
+        acc = (i % 3 == 0)
+        base = randn(300 + i, Co * k * k * Ci).to(gpu)
+        dw = base.clone() if acc else torch.full((Co * k * k * Ci,), float('nan'), device=gpu)
+        ref = base.clone() if acc else torch.empty(Co * k * k * Ci, device=gpu)
+        ops.conv_wgrad(d, x, dy, ref, acc)
+        items.append((d, x, dy, dw, acc)); refs.append(ref)
+    ops.conv_wgrad_grouped(items)
+    torch.cuda.synchronize()
+    for i, ((d, x, dy, dw, acc), ref) in enumerate(zip(items, refs)):
+        assert torch.isfinite(dw).all(), i
+        scale = float(ref.abs().max())
+        assert float((dw - ref).abs().max()) <= (2e-5 if dt == 'f32' else 1e-4) * scale, (i, shapes[i])

@@ -481,8 +481,9 @@ def test_g8_resnet101_forward_matches_reference(gpu):
         _close(m(x)[:, ::5], g['r101_y_eval'], tol=6e-2, name='y_eval_bf16')
 
 
-def test_full_size_resnet50_bf16_iteration_properties(gpu):
-    """BASELINE config 2 at full size (ResNet-50, 256x256, B=64 source + 64 target, bf16): no oracle finishes this in
+@pytest.mark.parametrize('arch,last_bn', [('resnet50', 'backbone.layer4.2.bn3'), ('resnet101', 'backbone.layer3.22.bn3')])
+def test_full_size_bf16_iteration_properties(gpu, arch, last_bn):
+    """BASELINE configs 2 and 3 at full size (ResNet-50 / ResNet-101, 256x256, B=64 source + 64 target, bf16): no oracle finishes this in
     seconds, so size-independent properties: finite losses, the shared B/C part of the network updates its running
     statistics twice (num_batches_tracked: A once + B/C twice = 3 per iteration; adversarial heads: 3 forwards),
     backbone.fc never receives a gradient, every stepped parameter moved and stays finite over two iterations."""
@@ -495,7 +496,7 @@ def test_full_size_resnet50_bf16_iteration_properties(gpu):
     mi355.set_compute_dtype('bf16')
     try:
         torch.manual_seed(1)
-        bb = models.resnet50(pretrained=False)
+        bb = models.__dict__[arch](pretrained=False)
         model = PoseResNetx9(bb, Upsampling(bb.out_features), 256, 21, num_head_layers=2, finetune=True).to(gpu)
         before = {k: v.detach().clone() for k, v in model.named_parameters()}
         step, opts, scheds = build_training(model)
@@ -507,7 +508,7 @@ def test_full_size_resnet50_bf16_iteration_properties(gpu):
         vals = [float(out[k]) for k in ('loss_s', 'loss_gf', 'loss_gt')]
         assert all(np.isfinite(v) for v in vals), vals
         sd = model.state_dict()
-        assert int(sd['backbone.layer4.2.bn3.num_batches_tracked']) == 3
+        assert int(sd[last_bn + '.num_batches_tracked']) == 3
         assert int(sd['upsampling.7.num_batches_tracked']) == 3
         assert int(sd['head.1.num_batches_tracked']) == 3
         assert int(sd['head_adv3.last_lay.6.num_batches_tracked']) == 3
