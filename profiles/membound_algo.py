@@ -71,5 +71,10 @@ ms, launches, flops, abytes = ops.prof_read()
 fam = {k: {'bytes_per_iteration': int(v)} for k, v in acc.items()}
 fam['conv_mfma'] = {'bytes_per_iteration': int(abytes), 'launches_per_iteration': int(launches), 'flops_per_iteration': flops}
 head = subprocess.run(['git', 'rev-parse', '--short', 'HEAD'], capture_output=True, text=True, cwd='/root/repo').stdout.strip()
+if not head:      # the GPU box receives a snapshot without .git: the commit is written next to this script before the run
+    try:
+        head = open('/root/repo/profiles/.head_for_pmc').read().strip()
+    except OSError:
+        head = ''
 print(json.dumps({'iterations_in_trace': int(sys.argv[1]), 'command': sys.argv[2] if len(sys.argv) > 2 else None, 'git_head': head or None,
                   'config': 'resnet50_256_b64_bf16', 'families': fam}, indent=1))
