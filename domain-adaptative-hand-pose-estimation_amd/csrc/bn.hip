@@ -4,6 +4,7 @@
 // (bitwise reproducible; no atomics).  Slice partials stay slice-major: a channel-major layout makes the finalize
 // kernels 35 % faster but the scattered 4-byte partial writes cost the statistics kernels twice that (measured).
 #include "common.h"
+#include "fp8_common.h"
 #include <stdlib.h>
 
 struct BnPlan { int cpr, TX, TY, colgroups, nslices, rows_per_slice; };
@@ -185,26 +186,34 @@ __global__ __launch_bounds__(256) void bn_finalize_wide_kernel(const float* __re
   scale_shift[c] = sc; scale_shift[C + c] = b - mean * sc;
 }
 
-template <typename T, bool EVAL>
+// Q8 (bf16 only, 'fp8' compute mode): besides y, the e4m3 copy q8 = saturate(y * q8_state[0]) of the values as stored (the
+// operand of the fp8 conv that consumes y: no stand-alone quantisation pass) and max |y| into q8_state[2] for the next scale.
+template <typename T, bool EVAL, bool Q8 = false>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, const T* __restrict__ res, T* __restrict__ y,
                                                         const float* __restrict__ scale_shift, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, const float* __restrict__ rm,
                                                         const float* __restrict__ rv, float eps, long rows, int C, int TX, int relu,
-                                                        unsigned char* __restrict__ mask) {
+                                                        unsigned char* __restrict__ mask, unsigned char* __restrict__ q8 = nullptr,
+                                                        float* __restrict__ q8_state = nullptr) {
   constexpr int CH = Chunk<T>::N;
+  static_assert(!Q8 || CH == 8, "fp8 side output: bf16 activations only");
   const int TY = 256 / TX;
   const int tx = threadIdx.x % TX, ty = threadIdx.x / TX;
   const int chunk = blockIdx.x * TX + tx;
-  if (chunk * CH >= C) return;
+  const bool colok = chunk * CH < C;
+  if (!colok && !Q8) return;                   // (Q8: every thread takes part in the block-wide amax at the end)
   const int cpr = C / CH;
   float sc[CH], sh[CH];
 #pragma unroll
   for (int e = 0; e < CH; ++e) {
     const int c = chunk * CH + e;
-    if (EVAL) { sc[e] = gamma[c] / sqrtf(rv[c] + eps); sh[e] = beta[c] - rm[c] * sc[e]; }
+    if (!colok) { sc[e] = 0.f; sh[e] = 0.f; }
+    else if (EVAL) { sc[e] = gamma[c] / sqrtf(rv[c] + eps); sh[e] = beta[c] - rm[c] * sc[e]; }
     else { sc[e] = scale_shift[c]; sh[e] = scale_shift[C + c]; }
   }
-  for (long r = (long)blockIdx.y * TY + ty; r < rows; r += (long)gridDim.y * TY) {
+  float qscale = 0.f, amax = 0.f; unsigned seen = 0;
+  if constexpr (Q8) { qscale = q8_state[0]; seen = fp8_amax_seen(q8_state); }
+  for (long r = (long)blockIdx.y * TY + ty; colok && r < rows; r += (long)gridDim.y * TY) {
     const size_t off = (size_t)r * C + (size_t)chunk * CH;
     float v[CH]; Chunk<T>::load(x + off, v);
 #pragma unroll
@@ -222,7 +231,17 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, 
 #pragma unroll
       for (int e = 0; e < CH; ++e) v[e] = v[e] < 0.f ? 0.f : v[e]; }   // keeps NaN, like ATen relu
     Chunk<T>::store(y + off, v);
+    if constexpr (Q8) {
+      float w[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { w[e] = (float)(T)v[e]; amax = fmaxf(amax, fabsf(w[e])); }      // the stored (rounded) values
+      // two neighbouring chunks of a row (lanes tx, tx+1: same row, always active together; C % 128 == 0) -> one 16-byte store
+      const uint2 o = pack8_fp8<false>(w, qscale);
+      const unsigned nx = __shfl_down(o.x, 1, 64), ny = __shfl_down(o.y, 1, 64);
+      if ((tx & 1) == 0) *reinterpret_cast<uint4*>(q8 + off) = make_uint4(o.x, o.y, nx, ny);
+    }
   }
+  if constexpr (Q8) fp8_record_amax(amax, q8_state, seen);
 }
 
 // -------------------------------------------------------------------------------- backward
@@ -338,26 +357,32 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
   if (coeff) { coeff[c] = g * is; coeff[C + c] = s1 * inv_rows; coeff[2 * C + c] = s2 * inv_rows; }
 }
 
-template <typename T, int RELU>
+// Q8: also the e5m2 copy of dx (operand of the fp8 input-gradient GEMM of the conv in front of this BatchNorm) + its amax
+template <typename T, int RELU, bool Q8 = false>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ dy, const T* __restrict__ x, const T* __restrict__ y,
                                                             const float* __restrict__ mean, const float* __restrict__ invstd,
                                                             const float* __restrict__ coeff, const float* __restrict__ beta,
                                                             T* __restrict__ dx, T* __restrict__ dres,
-                                                            long rows, int C, int TX, const unsigned char* __restrict__ mask) {
+                                                            long rows, int C, int TX, const unsigned char* __restrict__ mask,
+                                                            unsigned char* __restrict__ q8 = nullptr, float* __restrict__ q8_state = nullptr) {
   constexpr int CH = Chunk<T>::N;
   constexpr int relu = RELU;
+  static_assert(!Q8 || CH == 8, "fp8 side output: bf16 gradients only");
   const int TY = 256 / TX;
   const int tx = threadIdx.x % TX, ty = threadIdx.x / TX;
   const int chunk = blockIdx.x * TX + tx;
-  if (chunk * CH >= C) return;
+  const bool colok = chunk * CH < C;
+  if (!colok && !Q8) return;
   const int cpr = C / CH;
   float k0[CH], k1[CH], k2[CH], mu[CH], is[CH], sh[CH];
 #pragma unroll
   for (int e = 0; e < CH; ++e) {
-    const int c = chunk * CH + e;
+    const int c = colok ? chunk * CH + e : 0;
     k0[e] = coeff[c]; k1[e] = coeff[C + c]; k2[e] = coeff[2 * C + c]; mu[e] = mean[c]; is[e] = invstd[c];
     sh[e] = (relu == 2) ? beta[c] - mu[e] * k0[e] : 0.f;      // k0 = gamma*invstd = forward scale
   }
+  float qscale = 0.f, amax = 0.f; unsigned seen = 0;
+  if constexpr (Q8) { qscale = q8_state[0]; seen = fp8_amax_seen(q8_state); }
   auto finish = [&](size_t off, float (&g)[CH], float (&v)[CH], const float (&o)[CH], unsigned mb) {
     if (relu == 1) {
 #pragma unroll
@@ -372,10 +397,18 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
 #pragma unroll
     for (int e = 0; e < CH; ++e) v[e] = k0[e] * (g[e] - k1[e] - (v[e] - mu[e]) * is[e] * k2[e]);
     Chunk<T>::store(dx + off, v);
+    if constexpr (Q8) {
+      float w[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { w[e] = (float)(T)v[e]; amax = fmaxf(amax, fabsf(w[e])); }
+      const uint2 o = pack8_fp8<true>(w, qscale);
+      const unsigned nx = __shfl_down(o.x, 1, 64), ny = __shfl_down(o.y, 1, 64);
+      if ((tx & 1) == 0) *reinterpret_cast<uint4*>(q8 + off) = make_uint4(o.x, o.y, nx, ny);
+    }
   };
   // two rows per trip: twice the loads in flight per wave (the kernel is latency-, not issue-bound)
   const long stride = (long)gridDim.y * TY;
-  long r = (long)blockIdx.y * TY + ty;
+  long r = colok ? (long)blockIdx.y * TY + ty : rows;
   for (; r + stride < rows; r += 2 * stride) {
     const size_t off0 = (size_t)r * C + (size_t)chunk * CH, off1 = (size_t)(r + stride) * C + (size_t)chunk * CH;
     float g0[CH], v0[CH], o0[CH], g1[CH], v1[CH], o1[CH];
@@ -392,6 +425,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
     if (relu == 1) Chunk<T>::load(y + off, o);
     finish(off, g, v, o, relu == 3 ? (unsigned)mask[(size_t)r * cpr + chunk] : 0u);
   }
+  if constexpr (Q8) fp8_record_amax(amax, q8_state, seen);
 }
 
 __global__ __launch_bounds__(256) void colsum_finalize_kernel(const float* __restrict__ partial, int nslices, int C, float* out, int accumulate) {
@@ -410,6 +444,11 @@ __global__ __launch_bounds__(256) void colsum_finalize_kernel(const float* __res
 }
 
 // -------------------------------------------------------------------------------- host
+static int q8_check(const void* q8_out, const float* q8_state, int dtype, int C) {
+  if (!q8_out && !q8_state) return 0;
+  if (!q8_out || !q8_state || dtype != MI355_BF16 || C % 16) MI_FAIL(MI355_EINVAL, "bn: the fp8 side output needs both q8 pointers, bf16 activations and C %% 16 == 0");
+  return 0;
+}
 static int bn_check(long rows, int C, int dtype, int* CH) {
   if (dtype != MI355_F32 && dtype != MI355_BF16) MI_FAIL(MI355_EINVAL, "bn: bad dtype");
   *CH = dtype == MI355_BF16 ? 8 : 4;
@@ -430,8 +469,9 @@ static dim3 apply_grid(const BnPlan& p, long rows, bool backward = false) {
 extern "C" int mi355_bn_train_fwd(const void* x, const void* residual, void* y, const float* gamma, const float* beta,
                                   float* running_mean, float* running_var, int64_t* nbt, float* save_mean, float* save_invstd,
                                   long rows, int C, float eps, float momentum, int stat_updates, int relu, int dtype, void* ws,
-                                  size_t ws_bytes, void* relu_mask, void* stream) {
+                                  size_t ws_bytes, void* relu_mask, void* q8_out, float* q8_state, void* stream) {
   int CH; if (int e = bn_check(rows, C, dtype, &CH)) return e;
+  if (int e = q8_check(q8_out, q8_state, dtype, C)) return e;
   unsigned char* mk = reinterpret_cast<unsigned char*>(relu_mask);
   if (stat_updates < 0 || stat_updates > 8) MI_FAIL(MI355_EINVAL, "bn_train_fwd: stat_updates=%d", stat_updates);
   if (!ws || ws_bytes < mi355_bn_workspace(rows, C)) MI_FAIL(MI355_EWORKSPACE, "bn_train_fwd: workspace too small");
@@ -445,7 +485,8 @@ extern "C" int mi355_bn_train_fwd(const void* x, const void* residual, void* y, 
   hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 4)), dim3(256), 0, st, partial, p.nslices, C, gamma, beta, running_mean, running_var, nbt, save_mean, save_invstd, ss, eps, momentum, stat_updates);
   dim3 ga = apply_grid(p, rows);
   const float* nf = nullptr;
-  if (dtype == MI355_BF16) hipLaunchKernelGGL((bn_apply_kernel<bf16_t, false>), ga, dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)residual, (bf16_t*)y, (const float*)ss, nf, nf, nf, nf, eps, rows, C, p.TX, relu, mk);
+  if (q8_out) hipLaunchKernelGGL((bn_apply_kernel<bf16_t, false, true>), ga, dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)residual, (bf16_t*)y, (const float*)ss, nf, nf, nf, nf, eps, rows, C, p.TX, relu, mk, (unsigned char*)q8_out, q8_state);
+  else if (dtype == MI355_BF16) hipLaunchKernelGGL((bn_apply_kernel<bf16_t, false>), ga, dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)residual, (bf16_t*)y, (const float*)ss, nf, nf, nf, nf, eps, rows, C, p.TX, relu, mk);
   else hipLaunchKernelGGL((bn_apply_kernel<float, false>), ga, dim3(256), 0, st, (const float*)x, (const float*)residual, (float*)y, (const float*)ss, nf, nf, nf, nf, eps, rows, C, p.TX, relu, mk);
   MI_CHECK_LAUNCH("bn_train_fwd");
   return MI355_OK;
@@ -457,8 +498,9 @@ extern "C" int mi355_bn_train_fwd_partials(const void* x, const void* residual, 
                                            float* running_mean, float* running_var, int64_t* nbt, float* save_mean,
                                            float* save_invstd, long rows, int C, float eps, float momentum, int stat_updates,
                                            int relu, int dtype, const float* partial, int nslices, float* scale_shift,
-                                           void* relu_mask, void* stream) {
+                                           void* relu_mask, void* q8_out, float* q8_state, void* stream) {
   int CH; if (int e = bn_check(rows, C, dtype, &CH)) return e;
+  if (int e = q8_check(q8_out, q8_state, dtype, C)) return e;
   unsigned char* mk = reinterpret_cast<unsigned char*>(relu_mask);
   if (stat_updates < 0 || stat_updates > 8) MI_FAIL(MI355_EINVAL, "bn_train_fwd_partials: stat_updates=%d", stat_updates);
   if (!partial || nslices < 1 || !scale_shift) MI_FAIL(MI355_EINVAL, "bn_train_fwd_partials: partial / scale_shift missing");
@@ -469,7 +511,8 @@ extern "C" int mi355_bn_train_fwd_partials(const void* x, const void* residual, 
   else hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 4)), dim3(256), 0, st, partial, nslices, C, gamma, beta, running_mean, running_var, nbt, save_mean, save_invstd, scale_shift, eps, momentum, stat_updates);
   dim3 ga = apply_grid(p, rows);
   const float* nf = nullptr;
-  if (dtype == MI355_BF16) hipLaunchKernelGGL((bn_apply_kernel<bf16_t, false>), ga, dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)residual, (bf16_t*)y, (const float*)scale_shift, nf, nf, nf, nf, eps, rows, C, p.TX, relu, mk);
+  if (q8_out) hipLaunchKernelGGL((bn_apply_kernel<bf16_t, false, true>), ga, dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)residual, (bf16_t*)y, (const float*)scale_shift, nf, nf, nf, nf, eps, rows, C, p.TX, relu, mk, (unsigned char*)q8_out, q8_state);
+  else if (dtype == MI355_BF16) hipLaunchKernelGGL((bn_apply_kernel<bf16_t, false>), ga, dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)residual, (bf16_t*)y, (const float*)scale_shift, nf, nf, nf, nf, eps, rows, C, p.TX, relu, mk);
   else hipLaunchKernelGGL((bn_apply_kernel<float, false>), ga, dim3(256), 0, st, (const float*)x, (const float*)residual, (float*)y, (const float*)scale_shift, nf, nf, nf, nf, eps, rows, C, p.TX, relu, mk);
   MI_CHECK_LAUNCH("bn_train_fwd_partials");
   return MI355_OK;
@@ -491,17 +534,21 @@ extern "C" int mi355_bn_eval_fwd(const void* x, const void* residual, void* y, c
 
 static void launch_bwd_apply(int dtype, int relu, dim3 ga, hipStream_t st, const void* dy, const void* x, const void* y, const float* save_mean,
                              const float* save_invstd, const float* coeff, const float* beta, void* dx, void* dresidual, long rows, int C,
-                             int TX, const unsigned char* mk) {
+                             int TX, const unsigned char* mk, void* q8_out, float* q8_state) {
 #define MI_APP(T, R) hipLaunchKernelGGL((bn_bwd_apply_kernel<T, R>), ga, dim3(256), 0, st, (const T*)dy, (const T*)x, (const T*)y, save_mean, save_invstd, coeff, beta, (T*)dx, (T*)dresidual, rows, C, TX, mk)
+#define MI_APQ(R) hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16_t, R, true>), ga, dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)x, (const bf16_t*)y, save_mean, save_invstd, coeff, beta, (bf16_t*)dx, (bf16_t*)dresidual, rows, C, TX, mk, (unsigned char*)q8_out, q8_state)
 #define MI_APP4(T) do { if (relu == 0) MI_APP(T, 0); else if (relu == 1) MI_APP(T, 1); else if (relu == 2) MI_APP(T, 2); else MI_APP(T, 3); } while (0)
-  if (dtype == MI355_BF16) MI_APP4(bf16_t); else MI_APP4(float);
+  if (q8_out) { if (relu == 0) MI_APQ(0); else if (relu == 1) MI_APQ(1); else if (relu == 2) MI_APQ(2); else MI_APQ(3); }
+  else if (dtype == MI355_BF16) MI_APP4(bf16_t); else MI_APP4(float);
 #undef MI_APP4
+#undef MI_APQ
 #undef MI_APP
 }
 
 extern "C" int mi355_bn_bwd(const void* dy, const void* x, const void* y, const float* gamma, const float* beta, const float* save_mean,
                             const float* save_invstd, void* dx, void* dresidual, float* dgamma, float* dbeta, int accumulate,
-                            long rows, int C, int relu, int dtype, void* ws, size_t ws_bytes, const void* relu_mask, void* stream) {
+                            long rows, int C, int relu, int dtype, void* ws, size_t ws_bytes, const void* relu_mask, void* q8_out,
+                            float* q8_state, void* stream) {
   int CH; if (int e = bn_check(rows, C, dtype, &CH)) return e;
   if (!ws || ws_bytes < mi355_bn_workspace(rows, C)) MI_FAIL(MI355_EWORKSPACE, "bn_bwd: workspace too small");
   // relu: the mask comes from the bit mask the forward wrote (1 bit / element), else from y when it is given; without
@@ -521,7 +568,8 @@ extern "C" int mi355_bn_bwd(const void* dy, const void* x, const void* y, const 
 #undef MI_RED
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 4)), dim3(256), 0, st, partial, p.nslices, C, 1.0f / (float)rows, gamma, save_invstd, dgamma, dbeta, accumulate, coeff);
   dim3 ga = apply_grid(p, rows, true);
-  launch_bwd_apply(dtype, relu, ga, st, dy, x, y, save_mean, save_invstd, coeff, beta, dx, dresidual, rows, C, p.TX, mk);
+  if (int e = q8_check(q8_out, q8_state, dtype, C)) return e;
+  launch_bwd_apply(dtype, relu, ga, st, dy, x, y, save_mean, save_invstd, coeff, beta, dx, dresidual, rows, C, p.TX, mk, q8_out, q8_state);
   MI_CHECK_LAUNCH("bn_bwd");
   return MI355_OK;
 }
@@ -531,7 +579,7 @@ extern "C" int mi355_bn_bwd(const void* dy, const void* x, const void* y, const 
 extern "C" int mi355_bn_bwd_partials(const void* dy, const void* x, const void* y, const float* gamma, const float* beta,
                                      const float* save_mean, const float* save_invstd, void* dx, void* dresidual, float* dgamma,
                                      float* dbeta, int accumulate, long rows, int C, int relu, int dtype, const float* partial,
-                                     int nslices, float* coeff, const void* relu_mask, void* stream) {
+                                     int nslices, float* coeff, const void* relu_mask, void* q8_out, float* q8_state, void* stream) {
   int CH; if (int e = bn_check(rows, C, dtype, &CH)) return e;
   if (!partial || nslices < 1 || !coeff) MI_FAIL(MI355_EINVAL, "bn_bwd_partials: partial / coeff missing");
   const unsigned char* mk = reinterpret_cast<const unsigned char*>(relu_mask);
@@ -541,7 +589,8 @@ extern "C" int mi355_bn_bwd_partials(const void* dy, const void* x, const void* 
   BnPlan p = bn_plan(rows, C, CH);
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 4)), dim3(256), 0, st, partial, nslices, C, 1.0f / (float)rows, gamma, save_invstd, dgamma, dbeta, accumulate, coeff);
   dim3 ga = apply_grid(p, rows, true);
-  launch_bwd_apply(dtype, relu, ga, st, dy, x, y, save_mean, save_invstd, coeff, beta, dx, dresidual, rows, C, p.TX, mk);
+  if (int e = q8_check(q8_out, q8_state, dtype, C)) return e;
+  launch_bwd_apply(dtype, relu, ga, st, dy, x, y, save_mean, save_invstd, coeff, beta, dx, dresidual, rows, C, p.TX, mk, q8_out, q8_state);
   MI_CHECK_LAUNCH("bn_bwd_partials");
   return MI355_OK;
 }

@@ -10,35 +10,19 @@
 // scale derived from the previous amax while recording the current one; `mi355_fp8_amax` + `mi355_fp8_update_scale` give
 // the just-in-time form), and the fp8 weight pack ([O][T][I] and [I][T][O], per-tensor scale).
 #include "igemm_common.h"
+#include "fp8_common.h"
 #include <stdlib.h>
 
 typedef long i64_t;
 
-// ------------------------------------------------------------------------------------ quantisation
-// state[0] = scale (x_q = x * scale), state[1] = descale = 1 / scale, state[2] = amax seen since the last update (bits)
-__device__ __forceinline__ float clamp_fp8(float v, float lim) {   // saturate; NaN stays NaN
-  return v != v ? v : fminf(fmaxf(v, -lim), lim);
-}
-template <bool BF8>
-__device__ __forceinline__ unsigned pack4_fp8(float a, float b, float c, float d) {
-  constexpr float LIM = BF8 ? 57344.f : 448.f;
-  int w = 0;
-  if constexpr (BF8) {
-    w = __builtin_amdgcn_cvt_pk_bf8_f32(clamp_fp8(a, LIM), clamp_fp8(b, LIM), w, false);
-    w = __builtin_amdgcn_cvt_pk_bf8_f32(clamp_fp8(c, LIM), clamp_fp8(d, LIM), w, true);
-  } else {
-    w = __builtin_amdgcn_cvt_pk_fp8_f32(clamp_fp8(a, LIM), clamp_fp8(b, LIM), w, false);
-    w = __builtin_amdgcn_cvt_pk_fp8_f32(clamp_fp8(c, LIM), clamp_fp8(d, LIM), w, true);
-  }
-  return (unsigned)w;
-}
-
+// ------------------------------------------------------------------------------------ quantisation (helpers: fp8_common.h)
 // 16 input elements per thread-iteration -> one 16-byte fp8 chunk.  amax over |x| (before scaling) into state[2] via an
 // integer atomic max on the float bits (exact and order-independent).
 template <typename T, bool BF8, bool WRITE>
 __global__ __launch_bounds__(256) void quantize_fp8_kernel(const T* __restrict__ x, unsigned char* __restrict__ q, float* __restrict__ state, long n16) {
   constexpr int PER = Chunk<T>::N, NC = 16 / PER;
   const float scale = state[0];
+  const unsigned seen = fp8_amax_seen(state);
   float amax = 0.f;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (long)gridDim.x * blockDim.x) {
     float v[16];
@@ -59,15 +43,7 @@ __global__ __launch_bounds__(256) void quantize_fp8_kernel(const T* __restrict__
       reinterpret_cast<uint4*>(q)[i] = o;
     }
   }
-  // one atomic per BLOCK, and only when it can still raise the recorded value: atomics on one address serialise at
-  // ~12 ns each (8192 wave-level atomics made this kernel take 100 us whatever the tensor size)
-  __shared__ float red[4];
-  amax = block_max<4>(amax, red);
-  if (threadIdx.x == 0 && amax > 0.f) {
-    const unsigned bits = __float_as_uint(amax);
-    unsigned* slot = reinterpret_cast<unsigned*>(state) + 2;
-    if (bits > __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(slot, bits);
-  }
+  fp8_record_amax(amax, state, seen);
 }
 
 // scale := fmt_max / (amax * 2^margin) (1 when nothing was seen yet), descale := 1 / scale, amax := 0.  `n` states.
@@ -113,15 +89,15 @@ extern "C" int mi355_fp8_update_scale(float* states, int n, int stride_floats, i
   return MI355_OK;
 }
 
-// fp32 master [O][T][I] (conv-form) -> e4m3 wf [O][T][I] and wt [I][T][O], both * state[0].  I, O multiples of 16.
-__global__ __launch_bounds__(256) void pack_weights_fp8_kernel(const float* __restrict__ w, unsigned char* __restrict__ wf,
-                                                                unsigned char* __restrict__ wt, const float* __restrict__ state,
-                                                                int O, int T, int I) {
+// fp32 master [O][T][I] (conv-form) -> e4m3 wf [O][T][I] and wt [I][T][O], both * state[0].  I, O multiples of 32.
+// Also records amax(|w|) in state[2] (block-level atomic) for the next scale update (delayed scaling).
+__device__ __forceinline__ void pack_fp8_block(const float* __restrict__ w, unsigned char* __restrict__ wf, unsigned char* __restrict__ wt,
+                                               float* __restrict__ state, int O, int T, int I, int b) {
   __shared__ float tile[32][33];
   __shared__ float red[4];
   const float scale = state[0];
+  const unsigned seen = fp8_amax_seen(state);
   const int tiles_i = I / 32, tiles_o = O / 32;
-  const int b = blockIdx.x;
   const int tap = b / (tiles_i * tiles_o), r = b % (tiles_i * tiles_o);
   const int o0 = (r / tiles_i) * 32, i0 = (r % tiles_i) * 32;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;            // 32 x 8
@@ -134,23 +110,38 @@ __global__ __launch_bounds__(256) void pack_weights_fp8_kernel(const float* __re
     tile[ty + 8 * k][tx] = v * scale;
   }
   amax = block_max<4>(amax, red);                     // (contains the barriers that publish `tile`)
-  if (threadIdx.x == 0 && amax > 0.f) {               // amax of the master for the next scale update (delayed scaling)
-    const unsigned bits = __float_as_uint(amax);
-    unsigned* slot = reinterpret_cast<unsigned*>(const_cast<float*>(state)) + 2;
-    if (bits > __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(slot, bits);
-  }
+  if (threadIdx.x == 0 && amax > 0.f && __float_as_uint(amax) > seen) (void)atomicMax(reinterpret_cast<unsigned*>(state) + 2, __float_as_uint(amax));
   __syncthreads();
-  // wf rows: 32 o x 32 i -> each thread packs 4 consecutive i of one o
-  {
+  {   // wf rows: each thread packs 4 consecutive i of one o
     const int o = threadIdx.x >> 3, g = threadIdx.x & 7;
     const unsigned v = pack4_fp8<false>(tile[o][4 * g], tile[o][4 * g + 1], tile[o][4 * g + 2], tile[o][4 * g + 3]);
     *reinterpret_cast<unsigned*>(wf + ((size_t)(o0 + o) * T + tap) * I + i0 + 4 * g) = v;
   }
-  {
+  {   // wt rows: 4 consecutive o of one i
     const int i = threadIdx.x >> 3, g = threadIdx.x & 7;
     const unsigned v = pack4_fp8<false>(tile[4 * g][i], tile[4 * g + 1][i], tile[4 * g + 2][i], tile[4 * g + 3][i]);
     *reinterpret_cast<unsigned*>(wt + ((size_t)(i0 + i) * T + tap) * O + o0 + 4 * g) = v;
   }
+}
+__global__ __launch_bounds__(256) void pack_weights_fp8_kernel(const float* __restrict__ w, unsigned char* __restrict__ wf,
+                                                                unsigned char* __restrict__ wt, float* __restrict__ state,
+                                                                int O, int T, int I) {
+  pack_fp8_block(w, wf, wt, state, O, T, I, blockIdx.x);
+}
+// every fp8 conv weight of an optimizer group in ONE launch (delayed scales): items in device memory, block -> item by
+// binary search over the first-block prefix (as mi355_pack_weights_batched)
+__global__ __launch_bounds__(256) void pack_weights_fp8_batched_kernel(const mi355_pack8_item* __restrict__ items, int nitems) {
+  int lo = 0, hi = nitems - 1;
+  const int b = blockIdx.x;
+  while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (items[mid].blk0 <= b) lo = mid; else hi = mid - 1; }
+  const mi355_pack8_item it = items[lo];
+  pack_fp8_block(it.w, (unsigned char*)it.wf, (unsigned char*)it.wt, it.state, it.O, it.T, it.I, b - it.blk0);
+}
+extern "C" int mi355_pack_weights_fp8_batched(const mi355_pack8_item* items_dev, int nitems, int total_blocks, void* stream) {
+  if (!items_dev || nitems < 1 || total_blocks < 1) MI_FAIL(MI355_EINVAL, "pack_weights_fp8_batched: bad args");
+  hipLaunchKernelGGL(pack_weights_fp8_batched_kernel, dim3(total_blocks), dim3(256), 0, as_stream(stream), items_dev, nitems);
+  MI_CHECK_LAUNCH("pack_weights_fp8_batched");
+  return MI355_OK;
 }
 
 extern "C" int mi355_pack_weights_fp8(const float* w_master, void* wf, void* wt, float* state, int O, int T, int I, int margin, void* stream) {
@@ -161,7 +152,7 @@ extern "C" int mi355_pack_weights_fp8(const float* w_master, void* wf, void* wt,
     if (int e = mi355_fp8_update_scale(state, 1, 4, 0, margin, stream)) return e;
   }                       // margin < 0: the scale already in `state` (delayed scaling); the amax of w is recorded either way
   hipLaunchKernelGGL(pack_weights_fp8_kernel, dim3((O / 32) * (I / 32) * T), dim3(256), 0, as_stream(stream), w_master,
-                     (unsigned char*)wf, (unsigned char*)wt, (const float*)state, O, T, I);
+                     (unsigned char*)wf, (unsigned char*)wt, state, O, T, I);
   MI_CHECK_LAUNCH("pack_weights_fp8");
   return MI355_OK;
 }

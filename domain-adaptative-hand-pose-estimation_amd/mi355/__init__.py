@@ -54,6 +54,7 @@ SIGNATURES = {
     'mi355_fp8_quantize': (_I, [_P, _P, _P, _L, _I, _I, _I, _P]),
     'mi355_fp8_update_scale': (_I, [_P, _I, _I, _I, _I, _P]),
     'mi355_pack_weights_fp8': (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    'mi355_pack_weights_fp8_batched': (_I, [_P, _I, _I, _P]),
     'mi355_conv_fwd_fp8': (_I, [_D, _P, _I, _P, _P, _P, _P, _P, _P, _P, _Z, _P, _P]),
     'mi355_conv_dgrad_fp8': (_I, [_D, _P, _I, _P, _P, _P, _P, _I, _P, _P, _Z, _P, _P]),
     'mi355_conv_wgrad_workspace': (_Z, [_D]),
@@ -65,11 +66,11 @@ SIGNATURES = {
     'mi355_colsum_workspace': (_Z, [_L, _I]),
     'mi355_colsum': (_I, [_P, _P, _L, _I, _I, _I, _P, _Z, _P]),
     'mi355_bn_workspace': (_Z, [_L, _I]),
-    'mi355_bn_train_fwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _F, _F, _I, _I, _I, _P, _Z, _P, _P]),
-    'mi355_bn_train_fwd_partials': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _F, _F, _I, _I, _I, _P, _I, _P, _P, _P]),
+    'mi355_bn_train_fwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _F, _F, _I, _I, _I, _P, _Z, _P, _P, _P, _P]),
+    'mi355_bn_train_fwd_partials': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _F, _F, _I, _I, _I, _P, _I, _P, _P, _P, _P, _P]),
     'mi355_bn_eval_fwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _L, _I, _F, _I, _I, _P]),
-    'mi355_bn_bwd_partials': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _L, _I, _I, _I, _P, _I, _P, _P, _P]),
-    'mi355_bn_bwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _L, _I, _I, _I, _P, _Z, _P, _P]),
+    'mi355_bn_bwd_partials': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _L, _I, _I, _I, _P, _I, _P, _P, _P, _P, _P]),
+    'mi355_bn_bwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _L, _I, _I, _I, _P, _Z, _P, _P, _P, _P]),
     'mi355_maxpool_fwd': (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
     'mi355_maxpool_bwd': (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
     'mi355_nchw_to_nhwc': (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),

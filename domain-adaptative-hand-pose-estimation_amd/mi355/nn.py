@@ -37,6 +37,7 @@ def mark_grads_fresh(params):
         if p.grad is not None:
             p._mi_fresh = True
     _BWD_PARTIALS.clear()          # leftovers of a backward pass that never reached their BatchNorm
+    _GRAD_Q8.clear()               # ... or whose fp8 gradient copy no conv picked up
 
 
 def _param_version(p):
@@ -106,32 +107,50 @@ class _PackedFp8:
             # first pack: scale from this tensor; afterwards delayed scaling (weights move by lr per step): ONE launch
             ops.pack_weights_fp8(weight.detach(), O, T, I, self.state, self.wf, self.wt, jit=first)
             self.key = key
+            weight._mi_pack8 = (self, O, T, I)          # lets the optimizer refresh all fp8 copies of a group in one launch
         return self.wf, self.wt, self.state
 
 
+# fp8 copies of GRADIENT tensors written on the side by the kernel that produced them (BatchNorm backward): keyed by address;
+# the entry keeps the tensor alive, so the address cannot be reused while the entry exists (same scheme as _BWD_PARTIALS).
+_GRAD_Q8 = {}
+
+
+def _cached_q8(t, fmt):
+    """(q8, state) of an fp8 copy that already exists for tensor t, else None."""
+    hit = getattr(t, '_mi_q8', None)
+    if hit is not None and hit[2] == fmt and hit[3] == t._version:
+        return hit[0], hit[1]
+    ent = _GRAD_Q8.get(t.data_ptr())
+    if ent is not None and ent[3] == fmt and ent[0].shape == t.shape and ent[0].dtype == t.dtype and ent[0]._version == ent[4]:
+        return ent[1], ent[2]
+    return None
+
+
 class _Fp8Stream:
-    """Scaling state of one fp8 operand stream (a conv's input or output gradient): the first tensor is scaled just in
-    time, later ones with the scale derived from the amax of the previous uses (mi355.fp8_tick)."""
+    """Scaling state of one fp8 operand stream (a conv's input or output gradient, a BatchNorm's output or input gradient):
+    the first tensor is scaled just in time, later ones with the scale derived from the amax of the previous uses
+    (mi355.fp8_tick).  A tensor that already carries an fp8 copy (written by its producer, or by another consumer) is not
+    quantised again."""
 
     def __init__(self, fmt):
         self.fmt, self.state = fmt, None
 
-    def quantize(self, t):
-        # several convs read the same tensor (the neck output feeds three fp8 convs): quantise it once
-        hit = getattr(t, '_mi_q8', None)
-        if hit is not None and hit[2] == self.fmt and hit[3] == t._version:
-            return hit[0], hit[1]
-        q, st = self._quantize(t)
-        t._mi_q8 = (q, st, self.fmt, t._version)
-        return q, st
+    def ready(self, device):
+        return self.state is not None and self.state.device == device
 
-    def _quantize(self, t):
-        first = self.state is None or self.state.device != t.device
+    def quantize(self, t):
+        hit = _cached_q8(t, self.fmt)
+        if hit is not None:
+            return hit
+        first = not self.ready(t.device)
         if first:
             if torch.cuda.is_current_stream_capturing():
                 raise Mi355Error('fp8 scaling state is created on first use: run one eager iteration before capturing')
             self.state = _rt.fp8_alloc_state(t.device, self.fmt)
-        return ops.fp8_quantize(t, self.state, self.fmt, jit=first), self.state
+        q = ops.fp8_quantize(t, self.state, self.fmt, jit=first)
+        t._mi_q8 = (q, self.state, self.fmt, t._version)
+        return q, self.state
 
 
 _PACK_BATCHED = __import__('os').environ.get('MI355_PACK_BATCHED', '1') == '1'
@@ -166,6 +185,32 @@ def repack_params(params, cache):
         pk.key = (_param_version(p), dtype, Ipad)
 
 
+def repack_params_fp8(params, cache):
+    """The fp8 (e4m3) copies of every conv weight in `params` refreshed by ONE kernel right after the optimizer step (scales
+    from the amax of the previous pack: delayed scaling), instead of one launch per conv at the next forward."""
+    if not _PACK_BATCHED or not _rt.fp8_convs():
+        return
+    ents = [(p, p._mi_pack8) for p in params if getattr(p, '_mi_pack8', None) is not None and p._mi_pack8[0].wf is not None]
+    if not ents:
+        return
+    sig = tuple((p.data_ptr(), e[0].wf.data_ptr(), e[0].wt.data_ptr(), e[0].state.data_ptr()) for p, e in ents)
+    if cache.get('sig8') != sig:
+        if torch.cuda.is_current_stream_capturing():
+            return                                     # table not built yet: the convs repack lazily
+        import numpy as np
+        rec = np.zeros(len(ents), dtype=[('w', '<u8'), ('wf', '<u8'), ('wt', '<u8'), ('state', '<u8'), ('O', '<i4'), ('T', '<i4'),
+                                         ('I', '<i4'), ('blk0', '<i4')])
+        blk = 0
+        for i, (p, (pk, O, T, I)) in enumerate(ents):
+            rec[i] = (p.data_ptr(), pk.wf.data_ptr(), pk.wt.data_ptr(), pk.state.data_ptr(), O, T, I, blk)
+            blk += (O // 32) * (I // 32) * T
+        cache['tab8'] = torch.from_numpy(rec.view(np.uint8).copy()).to(ents[0][0].device)
+        cache['blocks8'], cache['sig8'] = blk, sig
+    ops.pack_weights_fp8_batched(cache['tab8'], len(ents), cache['blocks8'])
+    for p, (pk, O, T, I) in ents:
+        pk.key = (_param_version(p), O, T, I)
+
+
 def _chk_convform(weight):
     w = weight.detach()
     if not w.permute(0, 2, 3, 1).is_contiguous():
@@ -178,7 +223,11 @@ _FUSE_STATS = _os.environ.get('MI355_BN_STATS_FUSE', '1') == '1'      # A/B swit
 _FUSE_BNBWD = _os.environ.get('MI355_BN_BWD_FUSE', '0') == '1'        # opt-in: BN backward reduction in the dgrad epilogue (measured neutral)
 _SKIP_FUSE = _os.environ.get('MI355_SKIP_FUSE', '1') == '1'             # A/B switch: residual-fork gradient add inside dgrad
 _MASK_FROM_Y = _os.environ.get('MI355_BN_MASK_FROM_Y', '0') == '1'     # A/B switch: read y for every ReLU mask
-_RELU_BITMASK = _os.environ.get('MI355_BN_RELU_BITMASK', '1') == '1'   # A/B switch: bit mask instead of y for BN + residual + ReLU
+_RELU_BITMASK = _os.environ.get('MI355_BN_RELU_BITMASK', '1') == '1'
+# opt-in ('fp8' mode): BatchNorm writes the fp8 copies of y / dx its neighbouring convs consume on the side.  Measured NEGATIVE:
+# the extra byte stream costs the BatchNorm kernels +28 .. +80 % (profiles/bn_fp8_side_output_bench.py), more than the stand-alone
+# quantisation passes it removes and the fp8 1x1 convs it enables give back (ResNet-50, B=64: 36.0 vs 34.7 ms / iteration)
+_FP8_BN_SIDE = _os.environ.get('MI355_FP8_BN_SIDE', '0') == '1'   # A/B switch: bit mask instead of y for BN + residual + ReLU
 
 # dy tensors whose producing GEMM already reduced them for the BatchNorm backward: data_ptr -> (dy, (partial, nslices)).
 # The entry keeps dy alive, so its address cannot be reused while the entry exists; BatchNorm's backward pops it.
@@ -237,27 +286,42 @@ def _take_partial(mod, y):
     return y
 
 
+def _conv_forward(ctx, mod, x, bias, residual, stats_ok=True):
+    """conv forward on the bf16 / fp32 kernels or, in 'fp8' mode, on fp8 operands; leaves the plan on ctx."""
+    want = stats_ok and mod._want_stats() and residual is None
+    ctx.fp8 = mod._fp8_ok(x)
+    if ctx.fp8:
+        desc, ctx.desc8, wf8, _, sw = mod._plan_fp8(x)
+        x8, sx = mod._q_in.quantize(x)
+        y = ops.conv_fwd_fp8(ctx.desc8, x8, sx, wf8, sw, bias, residual, want_stats=want)
+        if want:
+            y, mod._last_partial = y
+    else:
+        desc, wf, _ = mod._plan(x)
+        if want:
+            y, mod._last_partial = ops.conv_fwd_stats(desc, x, wf, bias)
+        else:
+            y = ops.conv_fwd(desc, x, wf, bias, residual)
+    ctx.mod, ctx.desc = mod, desc
+    ctx.bn_src = mod._in_bn_src; mod._in_bn_src = None
+    return y
+
+
+def _conv_dgrad(ctx, x, dy, scale_dev=None, out=None, accumulate=False):
+    mod = ctx.mod
+    if ctx.fp8:
+        _, _, _, wt8, sw = mod._plan_fp8(x)
+        dy8, sdy = mod._q_dy.quantize(dy)
+        return ops.conv_dgrad_fp8(ctx.desc8, dy8, sdy, wt8, sw, scale_dev=scale_dev, out=out, accumulate=accumulate)
+    _, _, wt = mod._plan(x)
+    return _dgrad_for_bn(ctx.desc, dy, wt, ctx.bn_src, x, scale_dev=scale_dev, out=out, accumulate=accumulate)
+
+
 class _ConvFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, residual, mod, scale_dev, fan=None):
-        ctx.fan = fan
-        ctx.fp8 = mod._fp8_ok(x)
-        if ctx.fp8:
-            desc, desc8, wf8, _, sw = mod._plan_fp8(x)
-            x8, sx = mod._q_in.quantize(x)
-            want = mod._want_stats() and residual is None
-            y = ops.conv_fwd_fp8(desc8, x8, sx, wf8, sw, bias, residual, want_stats=want)
-            if want:
-                y, mod._last_partial = y
-            ctx.desc8 = desc8
-        else:
-            desc, wf, _ = mod._plan(x)
-            if mod._want_stats() and residual is None:
-                y, mod._last_partial = ops.conv_fwd_stats(desc, x, wf, bias)
-            else:
-                y = ops.conv_fwd(desc, x, wf, bias, residual)
-        ctx.mod, ctx.desc, ctx.scale_dev = mod, desc, scale_dev
-        ctx.bn_src = mod._in_bn_src; mod._in_bn_src = None
+        ctx.fan, ctx.scale_dev = fan, scale_dev
+        y = _conv_forward(ctx, mod, x, bias, residual)
         ctx.has_bias = bias is not None
         ctx.save_for_backward(x, weight, bias)
         return y
@@ -269,19 +333,11 @@ class _ConvFn(torch.autograd.Function):
         dy = _as_grad(dy, x.dtype)
         dx = None
         if ctx.needs_input_grad[1]:
-            mod._wgrad(desc, x, dy, weight)          # off the critical path: side stream
+            mod._wgrad(desc, x, dy, weight)
         if ctx.needs_input_grad[0]:
             fan = ctx.fan
             onto = fan is not None and fan.buf is not None and fan.buf.shape == x.shape and fan.buf.dtype == x.dtype
-            if ctx.fp8:
-                _, _, _, wt8, sw = mod._plan_fp8(x)
-                dy8, sdy = mod._q_dy.quantize(dy)
-                dx = ops.conv_dgrad_fp8(ctx.desc8, dy8, sdy, wt8, sw, scale_dev=ctx.scale_dev, out=fan.buf if onto else None,
-                                        accumulate=onto)
-            else:
-                _, _, wt = mod._plan(x)
-                dx = _dgrad_for_bn(desc, dy, wt, ctx.bn_src, x, scale_dev=ctx.scale_dev, out=fan.buf if onto else None,
-                                   accumulate=onto)
+            dx = _conv_dgrad(ctx, x, dy, scale_dev=ctx.scale_dev, out=fan.buf if onto else None, accumulate=onto)
             if onto:
                 dx = None
             elif fan is not None:
@@ -302,13 +358,7 @@ class _ConvSkipFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, mod):
-        desc, wf, _ = mod._plan(x)
-        if mod._want_stats():
-            y, mod._last_partial = ops.conv_fwd_stats(desc, x, wf, None)
-        else:
-            y = ops.conv_fwd(desc, x, wf, None, None)
-        ctx.mod, ctx.desc = mod, desc
-        ctx.bn_src = mod._in_bn_src; mod._in_bn_src = None
+        y = _conv_forward(ctx, mod, x, None, None)
         ctx.save_for_backward(x, weight)
         return y, x
 
@@ -321,11 +371,10 @@ class _ConvSkipFn(torch.autograd.Function):
             mod._wgrad(desc, x, dy, weight)
         dx = None
         if ctx.needs_input_grad[0]:
-            _, _, wt = mod._plan(x)
             if dskip is None:
-                dx = _dgrad_for_bn(desc, dy, wt, ctx.bn_src, x)
+                dx = _conv_dgrad(ctx, x, dy)
             else:       # dskip is a gradient buffer this library produced (BN / conv backward): accumulate in place
-                dx = _dgrad_for_bn(desc, dy, wt, ctx.bn_src, x, out=_as_grad(dskip, x.dtype), accumulate=True)
+                dx = _conv_dgrad(ctx, x, dy, out=_as_grad(dskip, x.dtype), accumulate=True)
         return dx, None, None
 
 
@@ -389,6 +438,13 @@ class _DeconvFn(torch.autograd.Function):
 class _BnFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, gamma, beta, residual, mod, relu, partial=None):
+        # 'fp8' mode: the e4m3 copy of y for the fp8 conv that consumes it is written by the apply pass itself (delayed scale);
+        # the very first tensor of the stream is scaled just in time by a stand-alone pass instead
+        q8 = None
+        emit = _FP8_BN_SIDE and _rt.fp8_convs() and x.dtype == torch.bfloat16 and mod.num_features % 128 == 0
+        if emit and mod._q_out.ready(x.device):
+            q8 = (torch.empty_like(x, dtype=torch.uint8), mod._q_out.state)
+        ctx.emit = emit
         # The backward's ReLU mask: recomputed from x when no residual was added; with a residual it is (y > 0), kept as a
         # bit mask the apply pass writes on the side (1/16 of the bytes of y) -- y itself only for the A/B switches
         keep_y = relu and (_MASK_FROM_Y or (residual is not None and (_FUSE_BNBWD or not _RELU_BITMASK)))
@@ -396,9 +452,11 @@ class _BnFn(torch.autograd.Function):
                                        (x.requires_grad or gamma.requires_grad)) else None
         y, mean, invstd = ops.bn_train_fwd(x, residual, gamma, beta, mod.running_mean, mod.running_var,
                                            mod.num_batches_tracked, mod.eps, mod.momentum, relu, _rt.bn_stat_updates,
-                                           partial=partial, relu_mask=mask)
+                                           partial=partial, relu_mask=mask, q8=q8)
+        mod._last_q8 = q8 if q8 is not None else ('jit' if emit else None)      # attached to the returned tensor by the module
         ctx.relu = relu
         ctx.mask = mask
+        ctx.mod = mod
         ctx.save_for_backward(x, y if keep_y else None, mean, invstd, gamma, beta)
         mod._last_src = (x, bool(keep_y), gamma, beta, mean, invstd, bool(relu))
         return y
@@ -416,8 +474,16 @@ class _BnFn(torch.autograd.Function):
             acc = acc_b if dg is None else acc
         ent = _BWD_PARTIALS.pop(dy.data_ptr(), None)       # dy already reduced by the GEMM epilogue that produced it?
         partial = ent[1] if (ent is not None and ent[0].shape == dy.shape and ent[0].dtype == dy.dtype) else None
+        q8, stream = None, ctx.mod._q_dx
+        emit = ctx.emit and _rt.fp8_convs() and ctx.needs_input_grad[0]
+        if emit and stream.ready(x.device):
+            q8 = (torch.empty_like(x, dtype=torch.uint8), stream.state)
         dx, dres = ops.bn_bwd(dy, x, y, gamma, mean, invstd, dg, db, acc, ctx.relu, ctx.needs_input_grad[3], beta=beta,
-                              partial=partial, relu_mask=ctx.mask)
+                              partial=partial, relu_mask=ctx.mask, q8=q8)
+        if emit:       # e5m2 copy of dx for the fp8 input-gradient GEMM of the conv in front (found again by address)
+            if q8 is None:
+                q8 = stream.quantize(dx)
+            _GRAD_Q8[dx.data_ptr()] = (dx, q8[0], q8[1], ops.E5M2, dx._version)
         return (dx if ctx.needs_input_grad[0] else None), None, None, dres, None, None, None
 
 
@@ -619,8 +685,11 @@ class Conv2d(nn.Module):
     def _fp8_ok(self, x):
         """fp8 operands for this conv?  'fp8' compute mode, a K-heavy kernel (3x3 and up: the 1x1 convs are HBM-bound, an
         extra quantisation pass would cost more than the GEMM gains) and channel counts the fp8 K tile (128) divides."""
-        return (_rt.fp8_convs() and self.mode == 'mfma' and self.kernel_size[0] >= 3 and x.dtype == torch.bfloat16 and
-                self.in_channels % 128 == 0 and self.out_channels % 128 == 0)
+        if not (_rt.fp8_convs() and self.mode == 'mfma' and x.dtype == torch.bfloat16 and
+                self.in_channels % 128 == 0 and self.out_channels % 128 == 0):
+            return False
+        # a 1x1 conv is HBM-bound: worth it only when its producer already wrote the fp8 copy of x (BatchNorm side output)
+        return self.kernel_size[0] >= 3 or _cached_q8(x, ops.E4M3) is not None
 
     def _plan_fp8(self, x):
         N, C, H, W = x.shape
@@ -679,12 +748,14 @@ class Conv2d(nn.Module):
     def forward_skip(self, x):
         """(conv(x), alias of x): for residual blocks, see _ConvSkipFn.  Bias-free MFMA convs only."""
         if not _SKIP_FUSE or self.mode != 'mfma' or self.bias is not None or getattr(x, '_mi_gl', None) is not None or \
-                self.in_channels != self._cin_pad(compute_dtype()) or \
-                (_rt.fp8_convs() and self.kernel_size[0] >= 3 and self.in_channels % 128 == 0 and self.out_channels % 128 == 0):
+                self.in_channels != self._cin_pad(compute_dtype()):
             return self.forward(x), x
         x = _as_feature(x, compute_dtype())
         self._in_bn_src = _bn_src_of(x)
         y, skip = _ConvSkipFn.apply(x, self.weight, self)
+        q8 = getattr(x, '_mi_q8', None)
+        if q8 is not None and q8[3] == x._version:     # the alias keeps the fp8 copy its producer wrote (down-sample conv)
+            skip._mi_q8 = (q8[0], q8[1], q8[2], skip._version)
         return _take_partial(self, y), skip
 
 
@@ -749,9 +820,11 @@ class BatchNorm2d(nn.Module):
         self.register_buffer('running_mean', torch.zeros(num_features))
         self.register_buffer('running_var', torch.ones(num_features))
         self.register_buffer('num_batches_tracked', torch.tensor(0, dtype=torch.long))
+        self._q_out, self._q_dx = _Fp8Stream(ops.E4M3), _Fp8Stream(ops.E5M2)      # 'fp8' mode: side outputs of y / dx
+        self._last_q8 = None
 
     def extra_repr(self):
-        return '{num_features}, eps={eps}, momentum={momentum}'.format(**self.__dict__)
+        return '{num_features}, eps={eps}, momentum={momentum}'.format(num_features=self.num_features, eps=self.eps, momentum=self.momentum)
 
     def forward(self, x, residual=None, relu=False):
         x = _as_feature(x, compute_dtype())
@@ -767,6 +840,11 @@ class BatchNorm2d(nn.Module):
                     partial = None
             y = _BnFn.apply(x, self.weight, self.bias, residual, self, bool(relu), partial)
             y._mi_bn_src, self._last_src = self._last_src, None     # lets the consumer conv's dgrad reduce dy for this BN
+            q8, self._last_q8 = self._last_q8, None
+            if q8 == 'jit':
+                self._q_out.quantize(y)                                # first tensor of the stream: scale from its own amax
+            elif q8 is not None:
+                y._mi_q8 = (q8[0], q8[1], ops.E4M3, y._version)        # fp8 copy written by the apply pass
             return y
         if torch.is_grad_enabled() and (x.requires_grad or self.weight.requires_grad):
             raise Mi355Error('BatchNorm2d in eval mode is forward-only on this path (wrap it in torch.no_grad())')

@@ -230,6 +230,11 @@ def pack_weights_fp8(w_master, O, T, I, state, wf=None, wt=None, jit=True):
     return wf, wt
 
 
+def pack_weights_fp8_batched(table, nitems, total_blocks):
+    """table: uint8 device tensor holding `nitems` mi355_pack8_item records."""
+    call('mi355_pack_weights_fp8_batched', ptr(table), int(nitems), int(total_blocks), stream_ptr())
+
+
 def make_desc_fp8(N, Hi, Wi, Ci, Co, kh, kw, stride, pad):
     Ho = (Hi + 2 * pad - kh) // stride + 1
     Wo = (Wi + 2 * pad - kw) // stride + 1
@@ -273,9 +278,11 @@ def bn_relu_mask(x):
 
 
 def bn_train_fwd(x, residual, gamma, beta, running_mean, running_var, nbt, eps, momentum, relu, stat_updates=1,
-                 partial=None, relu_mask=None):
+                 partial=None, relu_mask=None, q8=None):
     """partial: (buffer, nslices) from conv_fwd_stats / conv_dgrad_stats of the conv that produced x -> no statistics pass.
-    relu_mask: bn_relu_mask(x) buffer that receives the (y > 0) bits for the backward (instead of keeping y)."""
+    relu_mask: bn_relu_mask(x) buffer that receives the (y > 0) bits for the backward (instead of keeping y).
+    q8: (uint8 tensor shaped like y, fp8 state) -> also the e4m3 copy of y, scaled by state[0], and its amax."""
+    q8_out, q8_state = q8 if q8 is not None else (None, None)
     _chk_dev(x, gamma)
     N, C, H, W = x.shape
     rows = N * H * W
@@ -287,12 +294,12 @@ def bn_train_fwd(x, residual, gamma, beta, running_mean, running_var, nbt, eps, 
         ss = torch.empty(2 * C, dtype=torch.float32, device=x.device)
         call('mi355_bn_train_fwd_partials', ptr(x), ptr(residual), ptr(y), ptr(gamma), ptr(beta), ptr(running_mean),
              ptr(running_var), ptr(nbt), ptr(mean), ptr(invstd), rows, C, float(eps), float(momentum), int(stat_updates),
-             int(relu), dtype_code(x.dtype), ptr(buf), int(ns), ptr(ss), ptr(relu_mask), stream_ptr())
+             int(relu), dtype_code(x.dtype), ptr(buf), int(ns), ptr(ss), ptr(relu_mask), ptr(q8_out), ptr(q8_state), stream_ptr())
         return y, mean, invstd
     ws = workspace(load().mi355_bn_workspace(rows, C), x.device)
     call('mi355_bn_train_fwd', ptr(x), ptr(residual), ptr(y), ptr(gamma), ptr(beta), ptr(running_mean),
          ptr(running_var), ptr(nbt), ptr(mean), ptr(invstd), rows, C, float(eps), float(momentum), int(stat_updates), int(relu),
-         dtype_code(x.dtype), ptr(ws), ws.numel(), ptr(relu_mask), stream_ptr())
+         dtype_code(x.dtype), ptr(ws), ws.numel(), ptr(relu_mask), ptr(q8_out), ptr(q8_state), stream_ptr())
     return y, mean, invstd
 
 
@@ -305,9 +312,12 @@ def bn_eval_fwd(x, residual, gamma, beta, running_mean, running_var, eps, relu):
     return y
 
 
-def bn_bwd(dy, x, y, gamma, mean, invstd, dgamma, dbeta, accumulate, relu, want_dres, beta=None, partial=None, relu_mask=None):
+def bn_bwd(dy, x, y, gamma, mean, invstd, dgamma, dbeta, accumulate, relu, want_dres, beta=None, partial=None, relu_mask=None,
+           q8=None):
     """partial: (buffer, nslices) reduction partials from the GEMM epilogue that produced dy -> no reduction pass.
-    relu_mask: the bit mask the forward wrote (then y is not needed)."""
+    relu_mask: the bit mask the forward wrote (then y is not needed).
+    q8: (uint8 tensor shaped like dx, fp8 state) -> also the e5m2 copy of dx, scaled by state[0], and its amax."""
+    q8_out, q8_state = q8 if q8 is not None else (None, None)
     N, C, H, W = x.shape
     rows = N * H * W
     dx = nhwc_empty(N, C, H, W, x.dtype, x.device)
@@ -317,12 +327,12 @@ def bn_bwd(dy, x, y, gamma, mean, invstd, dgamma, dbeta, accumulate, relu, want_
         coeff = torch.empty(3 * C, dtype=torch.float32, device=x.device)
         call('mi355_bn_bwd_partials', ptr(dy), ptr(x), ptr(y), ptr(gamma), ptr(beta), ptr(mean), ptr(invstd), ptr(dx),
              ptr(dres), ptr(dgamma), ptr(dbeta), int(accumulate), rows, C, int(relu), dtype_code(x.dtype), ptr(buf), int(ns),
-             ptr(coeff), ptr(relu_mask), stream_ptr())
+             ptr(coeff), ptr(relu_mask), ptr(q8_out), ptr(q8_state), stream_ptr())
         return dx, dres
     ws = workspace(load().mi355_bn_workspace(rows, C), x.device)
     call('mi355_bn_bwd', ptr(dy), ptr(x), ptr(y), ptr(gamma), ptr(beta), ptr(mean), ptr(invstd), ptr(dx), ptr(dres),
          ptr(dgamma), ptr(dbeta), int(accumulate), rows, C, int(relu), dtype_code(x.dtype), ptr(ws), ws.numel(),
-         ptr(relu_mask), stream_ptr())
+         ptr(relu_mask), ptr(q8_out), ptr(q8_state), stream_ptr())
     return dx, dres
 
 

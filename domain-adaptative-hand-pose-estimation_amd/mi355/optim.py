@@ -11,7 +11,7 @@ from torch.optim import Optimizer
 
 import mi355 as _rt
 from . import ops
-from .nn import mark_grads_fresh, repack_params
+from .nn import mark_grads_fresh, repack_params, repack_params_fp8
 
 
 class FusedSGD(Optimizer):
@@ -176,6 +176,7 @@ class FusedSGD(Optimizer):
                 if not st:
                     p._mi_epoch = getattr(p, '_mi_epoch', 0) + 1
             repack_params(f['params'], f.setdefault('pack_cache', {}))     # packed conv copies: one launch per group
+            repack_params_fp8(f['params'], f['pack_cache'])
         if _rt.fp8_convs():
             _rt.fp8_tick()           # delayed scaling: the fp8 scales of the next pass from the amax values of this one
         return loss

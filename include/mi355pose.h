@@ -108,6 +108,10 @@ int mi355_conv_fwd_bnbwd(const mi355_conv_desc* d, const void* x, const void* w,
 int mi355_fp8_quantize(const void* x, void* q, float* state, long n, int src_dtype, int fmt, int write, void* stream);
 int mi355_fp8_update_scale(float* states, int n, int stride_floats, int fmt, int margin, void* stream);
 int mi355_pack_weights_fp8(const float* w, void* wf, void* wt, float* state, int O, int T, int I, int margin, void* stream);
+/* The same for many weights in one launch with the scales already in their states (delayed scaling): items in DEVICE memory,
+ * blk0 = first block of the item = sum over earlier items of (O/32)*(I/32)*T. */
+typedef struct mi355_pack8_item { const float* w; void* wf; void* wt; float* state; int O, T, I, blk0; } mi355_pack8_item;
+int mi355_pack_weights_fp8_batched(const mi355_pack8_item* items_dev, int nitems, int total_blocks, void* stream);
 /* mi355_conv_fwd / mi355_conv_dgrad with fp8 operands (d->dtype = MI355_FP8; channels contracted over: a multiple of 128):
  *   y  (bf16) = (conv(x8, w8)  * *descale_x  * *descale_w + bias) [+ residual]
  *   dx (bf16) = (dgrad(dy8, wT8) * *descale_dy * *descale_w) * (*scale_dev, optional) [+ dx when accumulate]
@@ -158,30 +162,34 @@ int mi355_colsum(const void* dy, float* out, long rows, int C, int dtype, int ac
  *      byte = (y > 0) of channel chunk*chunk_size + e.  The forward writes it; a backward given the mask takes the ReLU
  *      mask from it and reads neither y nor beta: 1/16 of the bytes of y in each of the two backward passes of a
  *      BatchNorm + residual + ReLU (the last BatchNorm of every residual block).
+ * q8_out / q8_state (nullable, both or none; bf16 only; 'fp8' compute mode): an fp8 copy of the result written on the side --
+ *      forward: q8 = e4m3(y * q8_state[0]), backward: q8 = e5m2(dx * q8_state[0]) -- and max |.| recorded in q8_state[2]
+ *      (mi355_fp8_quantize semantics): the consuming fp8 convolution then needs no quantisation pass of its own.
  */
 size_t mi355_bn_workspace(long rows, int C);
 int mi355_bn_train_fwd(const void* x, const void* residual, void* y, const float* gamma, const float* beta,
                        float* running_mean, float* running_var, int64_t* num_batches_tracked,
                        float* save_mean, float* save_invstd, long rows, int C, float eps, float momentum,
-                       int stat_updates, int relu, int dtype, void* ws, size_t ws_bytes, void* relu_mask, void* stream);
+                       int stat_updates, int relu, int dtype, void* ws, size_t ws_bytes, void* relu_mask, void* q8_out,
+                       float* q8_state, void* stream);
 /* mi355_bn_train_fwd without its statistics pass: the partials come from mi355_conv_fwd_stats / _dgrad_stats.
  * scale_shift: 2*C floats of scratch. */
 int mi355_bn_train_fwd_partials(const void* x, const void* residual, void* y, const float* gamma, const float* beta,
                                 float* running_mean, float* running_var, int64_t* num_batches_tracked,
                                 float* save_mean, float* save_invstd, long rows, int C, float eps, float momentum,
                                 int stat_updates, int relu, int dtype, const float* partial, int nslices,
-                                float* scale_shift, void* relu_mask, void* stream);
+                                float* scale_shift, void* relu_mask, void* q8_out, float* q8_state, void* stream);
 int mi355_bn_eval_fwd(const void* x, const void* residual, void* y, const float* gamma, const float* beta,
                       const float* running_mean, const float* running_var, long rows, int C, float eps,
                       int relu, int dtype, void* stream);
 int mi355_bn_bwd_partials(const void* dy, const void* x, const void* y, const float* gamma, const float* beta,
                           const float* save_mean, const float* save_invstd, void* dx, void* dresidual, float* dgamma,
                           float* dbeta, int accumulate, long rows, int C, int relu, int dtype, const float* partial,
-                          int nslices, float* coeff, const void* relu_mask, void* stream);
+                          int nslices, float* coeff, const void* relu_mask, void* q8_out, float* q8_state, void* stream);
 int mi355_bn_bwd(const void* dy, const void* x, const void* y, const float* gamma, const float* beta,
                  const float* save_mean, const float* save_invstd, void* dx, void* dresidual, float* dgamma, float* dbeta,
                  int accumulate, long rows, int C, int relu, int dtype, void* ws, size_t ws_bytes,
-                 const void* relu_mask, void* stream);
+                 const void* relu_mask, void* q8_out, float* q8_state, void* stream);
 
 /* ---------------------------------------------------------------- stem max-pool 3x3 s2 p1
  * Replaces nn.MaxPool2d(3,2,1) of the torchvision stem (uda/model/resnet.py:28).  argidx: uint8 window

@@ -279,3 +279,49 @@ def test_full_size_resnet101_512_fp8_iteration_properties(gpu, fp8_mode):
     for k, p in model.named_parameters():
         if not k.startswith('backbone.fc.'):
             assert torch.isfinite(p).all() and not torch.equal(p, before[k]), k
+
+
+def test_batchnorm_writes_the_fp8_copies_its_neighbours_consume(gpu, fp8_mode):
+    """'fp8' mode with the opt-in side outputs (MI355_FP8_BN_SIDE=1; off by default: measured slower end to end): BatchNorm's
+    apply pass writes the e4m3 copy of y (and its backward the e5m2 copy of dx) on the side, with the
+    delayed scale of its stream; the copies are bit-identical to a stand-alone quantisation of the stored tensors with the same
+    scale, the amax is recorded, and the neighbouring convs -- including a 1x1 -- pick them up instead of quantising again."""
+    from mi355 import ops
+    import mi355.nn as mnn
+    from mi355.nn import Conv2d, BatchNorm2d
+    mi355 = fp8_mode
+    mi355.set_compute_dtype('fp8')
+    side_before, mnn._FP8_BN_SIDE = mnn._FP8_BN_SIDE, True
+    conv_a = Conv2d(128, 128, 3, 1, 1, bias=False).to(gpu)
+    bn = BatchNorm2d(128).to(gpu)
+    conv_b = Conv2d(128, 256, 1, 1, 0, bias=False).to(gpu)          # 1x1: fp8 only because its input arrives with a copy
+    for i, m in enumerate((conv_a, bn, conv_b)):
+        fill_module_(m, 50 + i)
+        m.train()
+    calls = []
+    orig = ops.fp8_quantize
+    ops.fp8_quantize = lambda t, st, fmt=ops.E4M3, jit=False: (calls.append((tuple(t.shape), fmt, jit)), orig(t, st, fmt, jit))[1]
+    try:
+        for it in range(3):
+            x = _nhwc(randn(60 + it, 4, 128, 16, 16).to(gpu).to(torch.bfloat16)).requires_grad_(True)
+            del calls[:]
+            y = bn(conv_a(x), relu=True)
+            z = conv_b(y)
+            q8 = y._mi_q8
+            ref = (y.detach().float() * float(q8[1][0])).clamp(-448, 448).to(torch.float8_e4m3fn)
+            assert torch.equal(q8[0].view(torch.uint8), ref.view(torch.uint8)), it
+            fwd_calls = list(calls)
+            z.float().pow(2).sum().backward()
+            torch.cuda.synchronize()
+            if it == 0:      # streams are created on first use: stand-alone, just-in-time passes
+                assert [c[2] for c in fwd_calls] == [True, True] and len(calls) >= 4
+            else:            # steady state: only conv_a's own input x (no producer) and the loss gradient (no BatchNorm behind conv_b)
+                assert [(c[0], c[1]) for c in fwd_calls] == [((4, 128, 16, 16), ops.E4M3)], fwd_calls
+                assert [(c[0], c[1]) for c in calls[len(fwd_calls):]] == [((4, 256, 16, 16), ops.E5M2)], calls
+                assert float(bn._q_out.state[2:3].view(torch.int32).view(torch.float32)) == float(y.detach().float().abs().max())
+            assert torch.isfinite(x.grad).all() and torch.isfinite(conv_a.weight.grad).all()
+            mi355.fp8_tick()
+            mnn.mark_grads_fresh(list(conv_a.parameters()) + list(bn.parameters()) + list(conv_b.parameters()))
+    finally:
+        ops.fp8_quantize = orig
+        mnn._FP8_BN_SIDE = side_before
