@@ -169,11 +169,12 @@ class DAStep:
             o.zero_grad()
         with _rt.grouped_wgrads():
             y_s, y_s_adv, y_s_adv2, y_s_adv3, _ = m(b['x_s'])
-            loss_s = 2 * c['kl'](y_s, b['label_s'], b['w_s']) + \
-                4 * c['rd2'](y_s, y_s_adv2, None, b['w_s'], mode='min') + \
-                4 * c['rd'](y_s, y_s_adv, None, b['w_s'], mode='min') + \
-                4 * c['rd1'](y_s, y_s_adv3, b['w_s'], mode='min')
-            loss_s.backward()
+            # the coefficients of train1.py:384-387 ride inside the loss kernels (scale=), the total's gradient is the unit scalar
+            loss_s = c['kl'](y_s, b['label_s'], b['w_s'], scale=2) + \
+                c['rd2'](y_s, y_s_adv2, None, b['w_s'], mode='min', scale=4) + \
+                c['rd'](y_s, y_s_adv, None, b['w_s'], mode='min', scale=4) + \
+                c['rd1'](y_s, y_s_adv3, b['w_s'], mode='min', scale=4)
+            loss_s.backward(_rt.unit_grad(loss_s))
         _rt.join_side()
         self.out.update(loss_s=loss_s.detach(), y_s=y_s.detach(), y_s_adv=y_s_adv.detach())
 
@@ -193,16 +194,16 @@ class DAStep:
             y_t_adv, y_t_adv2, y_t_adv3 = m.adv_heads(f_t.detach())
         else:
             y_t, y_t_adv, y_t_adv2, y_t_adv3, _ = m(b['x_t'])
-        loss1 = to * c['rd1'](y_t, y_t_adv3, b['w_t'], mode='max')
+        loss1 = c['rd1'](y_t, y_t_adv3, b['w_t'], mode='max', scale=0.3 * to)
         H = y_t.shape[-1]
         target5 = ops.bilinear_up(y_t_adv3.detach(), H, 0.5)               # 0.5 * up(y_adv3) ...
         target5 = ops.bilinear_up(y_t_adv2.detach(), H, 1.0, out=target5)   # ... + up(y_adv2)   (train1.py:410-424)
         target0 = ops.bilinear_up(y_t_adv3.detach(), H // 2)
-        loss2 = to * c['rd'](y_t, y_t_adv, target5, b['w_t'], mode='max')
-        loss3 = to * c['rd2'](y_t, y_t_adv2, target0, b['w_t'], mode='max')
-        loss_gf = 0.3 * loss1 + 1 * loss2 + 0.3 * loss3
+        loss2 = c['rd'](y_t, y_t_adv, target5, b['w_t'], mode='max', scale=to)
+        loss3 = c['rd2'](y_t, y_t_adv2, target0, b['w_t'], mode='max', scale=0.3 * to)
+        loss_gf = loss1 + loss2 + loss3                 # = 0.3 to rd1 + to rd + 0.3 to rd2   (train1.py:426-432)
         with _rt.grouped_wgrads():
-            loss_gf.backward()
+            loss_gf.backward(_rt.unit_grad(loss_gf))
         _rt.join_side()
         self.out.update(loss_gf=loss_gf.detach())
 
@@ -223,11 +224,11 @@ class DAStep:
                 y_t_adv, y_t_adv2, y_t_adv3 = m.adv_heads(f_t)
             else:
                 y_t, y_t_adv, y_t_adv2, y_t_adv3, _ = m(b['x_t'])
-            loss1 = to * c['rd2'](y_t, y_t_adv2, None, b['w_t'], mode='min')
-            loss2 = to * c['rd'](y_t, y_t_adv, None, b['w_t'], mode='min')
-            loss_gt = 0.3 * loss1 + 1 * loss2
+            loss1 = c['rd2'](y_t, y_t_adv2, None, b['w_t'], mode='min', scale=0.3 * to)
+            loss2 = c['rd'](y_t, y_t_adv, None, b['w_t'], mode='min', scale=to)
+            loss_gt = loss1 + loss2                     # = 0.3 to rd2 + to rd   (train1.py:443-448)
             with _rt.grouped_wgrads():
-                loss_gt.backward()
+                loss_gt.backward(_rt.unit_grad(loss_gt))
             _rt.join_side()
         finally:
             if self.skip:

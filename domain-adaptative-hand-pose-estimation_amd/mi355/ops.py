@@ -433,8 +433,8 @@ def softargmax(hm, beta=100.0, out_scale=4.0):
     return uv
 
 
-def kl_heatmap(pred, target, weight, eps, want_grad):
-    """Returns (loss_rows [B,K], unit_grad [B,K,H,W] or None); unit_grad = d(mean over B*K)/d pred."""
+def kl_heatmap(pred, target, weight, eps, want_grad, coeff=1.0):
+    """Returns (loss_rows [B,K], unit_grad [B,K,H,W] or None); unit_grad = d(coeff * mean over B*K)/d pred."""
     pred, target = _hm(pred), _hm(target)
     B, K, H, W = pred.shape
     if tuple(target.shape) != (B, K, H, W):
@@ -444,7 +444,7 @@ def kl_heatmap(pred, target, weight, eps, want_grad):
     if weight is not None:
         weight = weight.reshape(B, K).float().contiguous()
     call('mi355_kl_heatmap', ptr(pred), ptr(target), ptr(weight), float(eps), ptr(rows), ptr(g), B * K, H * W,
-         1.0 / (B * K), stream_ptr())
+         float(coeff) / (B * K), stream_ptr())
     return rows, g
 
 

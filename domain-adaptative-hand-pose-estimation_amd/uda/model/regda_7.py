@@ -170,7 +170,7 @@ class _Disparity(nn.Module):
         self.criterion = criterion
         self.pseudo_label_generator = pseudo_label_generator
 
-    def _run(self, y, y_adv, y_adv2, weight, mode):
+    def _run(self, y, y_adv, y_adv2, weight, mode, scale=1.0):
         assert mode in ['min', 'max']
         gen = self.pseudo_label_generator
         # only the label the mode needs is materialised (the reference builds both and drops one)
@@ -178,28 +178,30 @@ class _Disparity(nn.Module):
                             normalise=(2 if (self.normalise and self.guard_empty_maps) else self.normalise),
                             want_gt=(mode == 'min'), want_gf=(mode == 'max'))
         self.ground_truth, self.ground_false = gt, gf
-        return self.criterion(y_adv, gt if mode == 'min' else gf, weight)
+        if scale == 1.0:
+            return self.criterion(y_adv, gt if mode == 'min' else gf, weight)
+        return self.criterion(y_adv, gt if mode == 'min' else gf, weight, scale=scale)
 
 
 class RegressionDisparityx1(_Disparity):
     """Level-2 (16x16) disparity: gf = clip(1 - 10 gt, 0, 1), no max-normalisation."""
     kind, normalise = 1, False
 
-    def forward(self, y, y_adv, weight=None, mode='min'):
-        return self._run(y, y_adv, None, weight, mode)
+    def forward(self, y, y_adv, weight=None, mode='min', scale=1.0):
+        return self._run(y, y_adv, None, weight, mode, scale)
 
 
 class RegressionDisparityx5(_Disparity):
     """Level-1 (32x32): gf = clip(1 - 10 gt, 0, 1) [+ y_adv2 - 100 gt, clipped], divided by its per-map max."""
     kind, normalise = 1, True
 
-    def forward(self, y, y_adv, y_adv2, weight=None, mode='min'):
-        return self._run(y, y_adv, y_adv2, weight, mode)
+    def forward(self, y, y_adv, y_adv2, weight=None, mode='min', scale=1.0):
+        return self._run(y, y_adv, y_adv2, weight, mode, scale)
 
 
 class RegressionDisparityx6(_Disparity):
     """Level-0 (64x64): gf = clip(clip(sum_k gt_k, 0, 1) - 10 gt, 0, 1) [+ y_adv2 - 100 gt, clipped], / per-map max."""
     kind, normalise = 2, True
 
-    def forward(self, y, y_adv, y_adv2, weight=None, mode='min'):
-        return self._run(y, y_adv, y_adv2, weight, mode)
+    def forward(self, y, y_adv, y_adv2, weight=None, mode='min', scale=1.0):
+        return self._run(y, y_adv, y_adv2, weight, mode, scale)
