@@ -34,7 +34,9 @@ extern "C" size_t mi355_bn_workspace(long rows, int C) {
     if (p.nslices > ns) ns = p.nslices;
     if (q.nslices > ns) ns = q.nslices;
   }
-  return ((size_t)ns * C * 3 + 4 * (size_t)C) * sizeof(float);
+  size_t n = (size_t)ns * C * 3;
+  if (n < 32768) n = 32768;              // the resident backward's partials: <= 256 blocks x 64 channels x 2 sums
+  return (n + 4 * (size_t)C) * sizeof(float);
 }
 extern "C" size_t mi355_colsum_workspace(long rows, int C) { return mi355_bn_workspace(rows, C); }
 
@@ -428,6 +430,171 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
   if constexpr (Q8) fp8_record_amax(amax, q8_state, seen);
 }
 
+// -------------------------------------------------------------------------------- backward, tensor resident in LDS
+// Small tensors (x and dy together within the chip's LDS: <= 16.8 MB each at 256 CUs x 160 KB) take ONE launch instead of
+// reduce + finalize + apply: a block per CU holds its [rows / R][64 or 32 channels] tile of x and dy in LDS between the
+// reduction and the apply pass, so both tensors are read from HBM once (3 tensor passes instead of 5) and two launch
+// boundaries disappear.  The R blocks of a channel group exchange their partial sums through device memory inside the launch
+// (guide, Guideline 16 counter form: write-through `sc1` partial stores drained by every storing wave, one agent-scope
+// arrive add per block, one relaxed poller per block with a bounded spin, `sc1` loads of the partials; the sums are folded
+// in a fixed order: bitwise reproducible).  All blocks must be resident together: the grid never exceeds the CU count.
+struct BnResArgs {
+  const void* dy; const void* x; const float* mean; const float* invstd; const float* gamma; const float* beta;
+  void* dx; void* dres; float* dgamma; float* dbeta; const unsigned char* mask;
+  float* partial;                       // [G][R][2 * channels per group]
+  long rows; int C, G, R, rpb, accumulate; float inv_rows;
+};
+// One arrival counter per grid size, never reset: a launch of n blocks moves it from one multiple of n to the next, so a
+// block that drew ticket v waits for the counter to reach (v / n + 1) * n (wrap-safe compare).  Launches of this kernel on
+// one device must not overlap in time (this library issues them on one stream; MI355_BN_RESIDENT=0 otherwise).
+#define BN_RES_MAXBLK 1024
+__device__ unsigned bn_res_sync[BN_RES_MAXBLK + 4];     // [n] arrivals of the n-block launches; [0]: spins that gave up
+
+__device__ __forceinline__ void bn_res_grid_barrier(unsigned nblk, int t) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every wave: its sc1 partial stores have left
+  __syncthreads();
+  if (t == 0) {
+    unsigned* st = bn_res_sync + nblk;
+    const unsigned v = __hip_atomic_fetch_add(st, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned target = (v / nblk + 1u) * nblk;
+    if (v + 1u != target) {               // (the last arriver has nothing to wait for)
+      unsigned spins = 0;
+      while ((int)(__hip_atomic_load(st, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
+        __builtin_amdgcn_s_sleep(4);
+        if (++spins > (1u << 19)) {       // ~0.3 s: a block that never became resident -- give up (results invalid, counted)
+          __hip_atomic_fetch_add(bn_res_sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          break;
+        }
+      }
+    }
+  }
+  __syncthreads();
+}
+
+template <typename T, int RELU>
+__global__ __launch_bounds__(1024) void bn_bwd_resident_kernel(BnResArgs p) {
+  constexpr int CH = Chunk<T>::N, GC = 8 * CH, NT = 1024, RL = NT / 8, NW = NT / 64, NL = NT / (GC * 2);
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int t = threadIdx.x, tx = t & 7, ty = t >> 3, lane = t & 63, wave = t >> 6;
+  const int g = blockIdx.x % p.G, r = blockIdx.x / p.G;
+  const long row0 = (long)r * p.rpb;
+  long row1 = row0 + p.rpb; if (row1 > p.rows) row1 = p.rows;
+  const int nrows = row1 > row0 ? (int)(row1 - row0) : 0;
+  uint4* xs = reinterpret_cast<uint4*>(smem);
+  uint4* ds = xs + (size_t)p.rpb * 8;
+  float* red = reinterpret_cast<float*>(ds + (size_t)p.rpb * 8);     // [NW][GC][2], later [NL][GC*2]
+  float* tot = red + NW * GC * 2;                                    // [GC*2]
+  const T* __restrict__ X = reinterpret_cast<const T*>(p.x);
+  const T* __restrict__ DY = reinterpret_cast<const T*>(p.dy);
+  const int C = p.C, cpr = C / CH, c0 = g * GC + tx * CH, chunk = c0 / CH;
+  float mu[CH], is[CH], sc[CH], sft[CH], s1[CH], s2[CH];
+#pragma unroll
+  for (int e = 0; e < CH; ++e) {
+    mu[e] = p.mean[c0 + e]; is[e] = p.invstd[c0 + e]; s1[e] = 0.f; s2[e] = 0.f;
+    sc[e] = p.gamma[c0 + e] * is[e];                                  // forward scale (bn_finalize_kernel)
+    sft[e] = (RELU == 2) ? p.beta[c0 + e] - mu[e] * sc[e] : 0.f;
+  }
+  // ---- pass 1: HBM -> LDS, per-thread sums over its rows (four rows in flight per thread)
+  for (int base = ty; base < nrows; base += 4 * RL) {
+    uint4 qx[4], qd[4]; unsigned mk[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int lr = base + k * RL;
+      if (lr < nrows) {
+        const size_t off = (size_t)(row0 + lr) * C + c0;
+        qx[k] = *reinterpret_cast<const uint4*>(X + off); qd[k] = *reinterpret_cast<const uint4*>(DY + off);
+        mk[k] = (RELU == 3) ? (unsigned)p.mask[(size_t)(row0 + lr) * cpr + chunk] : 0u;
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int lr = base + k * RL;
+      if (lr < nrows) {
+        xs[lr * 8 + tx] = qx[k]; ds[lr * 8 + tx] = qd[k];
+        float v[CH], gq[CH]; Chunk<T>::unpack(qx[k], v); Chunk<T>::unpack(qd[k], gq);
+#pragma unroll
+        for (int e = 0; e < CH; ++e) {
+          if (RELU == 2) gq[e] = (v[e] * sc[e] + sft[e]) > 0.f ? gq[e] : 0.f;
+          if (RELU == 3) gq[e] = ((mk[k] >> e) & 1u) ? gq[e] : 0.f;
+          s1[e] += gq[e]; s2[e] += gq[e] * ((v[e] - mu[e]) * is[e]);
+        }
+      }
+    }
+  }
+  // fold the row lanes: the 8 of a wave by xor shuffles, the NW waves in wave order through LDS
+#pragma unroll
+  for (int o = 8; o < 64; o <<= 1) {
+#pragma unroll
+    for (int e = 0; e < CH; ++e) { s1[e] += __shfl_xor(s1[e], o, 64); s2[e] += __shfl_xor(s2[e], o, 64); }
+  }
+  if (lane < 8) {
+#pragma unroll
+    for (int e = 0; e < CH; ++e) { red[(wave * GC + tx * CH + e) * 2] = s1[e]; red[(wave * GC + tx * CH + e) * 2 + 1] = s2[e]; }
+  }
+  __syncthreads();
+  float* part = p.partial + ((size_t)g * p.R) * (GC * 2);
+  if (t < GC * 2) {
+    float a = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) a += red[w * GC * 2 + t];
+    __hip_atomic_store(part + (size_t)r * (GC * 2) + t, a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // sc1: write-through
+  }
+  bn_res_grid_barrier((unsigned)(p.G * p.R), t);
+  // ---- the group's totals: NL lanes per value over the R blocks (fixed order), then the lanes in order
+  {
+    // sc1 buffer loads (aux 16), eight in flight per thread: atomic loads would be waited for one at a time
+    const int i = t % (GC * 2), s = t / (GC * 2);
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(part, 0, (unsigned)(p.R * GC * 2 * 4), 0x00020000);
+    float a = 0.f;
+    for (int rr0 = s; rr0 < p.R; rr0 += 8 * NL) {
+      float q[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int rr = rr0 + k * NL;
+        q[k] = rr < p.R ? __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, (rr * (GC * 2) + i) * 4, 0, 16)) : 0.f;
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) a += q[k];
+    }
+    red[s * GC * 2 + i] = a;
+  }
+  __syncthreads();
+  if (t < GC * 2) {
+    float a = 0.f;
+#pragma unroll
+    for (int s = 0; s < NL; ++s) a += red[s * GC * 2 + t];
+    tot[t] = a;
+  }
+  __syncthreads();
+  float k1[CH], k2[CH];
+#pragma unroll
+  for (int e = 0; e < CH; ++e) { s1[e] = tot[(tx * CH + e) * 2]; s2[e] = tot[(tx * CH + e) * 2 + 1]; k1[e] = s1[e] * p.inv_rows; k2[e] = s2[e] * p.inv_rows; }
+  if (r == 0 && ty == 0) {
+#pragma unroll
+    for (int e = 0; e < CH; ++e) {
+      if (p.dbeta) p.dbeta[c0 + e] = (p.accumulate ? p.dbeta[c0 + e] : 0.f) + s1[e];
+      if (p.dgamma) p.dgamma[c0 + e] = (p.accumulate ? p.dgamma[c0 + e] : 0.f) + s2[e];
+    }
+  }
+  // ---- pass 2: LDS -> dx (and the masked dy for the residual branch)
+  T* __restrict__ DX = reinterpret_cast<T*>(p.dx);
+  T* __restrict__ DR = reinterpret_cast<T*>(p.dres);
+  for (int lr = ty; lr < nrows; lr += RL) {
+    const size_t off = (size_t)(row0 + lr) * C + c0;
+    float v[CH], gq[CH]; Chunk<T>::unpack(xs[lr * 8 + tx], v); Chunk<T>::unpack(ds[lr * 8 + tx], gq);
+    const unsigned mb = (RELU == 3) ? (unsigned)p.mask[(size_t)(row0 + lr) * cpr + chunk] : 0u;
+#pragma unroll
+    for (int e = 0; e < CH; ++e) {
+      if (RELU == 2) gq[e] = (v[e] * sc[e] + sft[e]) > 0.f ? gq[e] : 0.f;
+      if (RELU == 3) gq[e] = ((mb >> e) & 1u) ? gq[e] : 0.f;
+    }
+    if (DR) Chunk<T>::store(DR + off, gq);
+#pragma unroll
+    for (int e = 0; e < CH; ++e) v[e] = sc[e] * (gq[e] - k1[e] - (v[e] - mu[e]) * is[e] * k2[e]);
+    Chunk<T>::store(DX + off, v);
+  }
+}
+
 __global__ __launch_bounds__(256) void colsum_finalize_kernel(const float* __restrict__ partial, int nslices, int C, float* out, int accumulate) {
   const int lane = threadIdx.x & 63;
   const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -532,6 +699,53 @@ extern "C" int mi355_bn_eval_fwd(const void* x, const void* residual, void* y, c
   return MI355_OK;
 }
 
+// ---- resident backward: plan + launch (returns false when the tensor does not fit / the mode is not covered)
+struct BnResPlan { int G, R, rpb; size_t lds; };
+static bool bn_resident_plan(long rows, int C, int CH, BnResPlan* q) {
+  static const bool on = !(getenv("MI355_BN_RESIDENT") && atoi(getenv("MI355_BN_RESIDENT")) == 0);
+  if (!on) return false;
+  static int ncu = 0; static size_t max_lds = 0;
+  if (!ncu) {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return false;
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) != hipSuccess) return false;
+    max_lds = (size_t)v;
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return false;
+    ncu = v;
+  }
+  const int GC = 8 * CH;
+  if (C % GC) return false;
+  static const long min_bytes = getenv("MI355_BN_RESIDENT_MIN") ? atol(getenv("MI355_BN_RESIDENT_MIN")) : 0;
+  if (rows * C * (16 / CH) < min_bytes) return false;       // (small tensors: three short launches beat the in-launch exchange)
+  q->G = C / GC;
+  if (q->G > ncu) return false;
+  long R = ncu / q->G; if (R > rows) R = rows;
+  q->rpb = (int)((rows + R - 1) / R);
+  q->R = (int)((rows + q->rpb - 1) / q->rpb);
+  q->lds = (size_t)q->rpb * 8 * 16 * 2 + (size_t)(16 * GC * 2 + GC * 2) * sizeof(float);
+  return q->lds <= max_lds && (size_t)q->G * q->R <= (size_t)ncu && q->G * q->R <= BN_RES_MAXBLK;
+}
+template <typename T, int RELU>
+static int bn_resident_launch(const BnResArgs& a, size_t lds, hipStream_t st) {
+  static size_t raised = 0;
+  auto kern = bn_bwd_resident_kernel<T, RELU>;
+  if (lds > raised) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      MI_FAIL(MI355_ELAUNCH, "bn_bwd: cannot raise the dynamic LDS limit to %zu bytes", lds);
+    raised = lds;
+  }
+  hipLaunchKernelGGL(kern, dim3(a.G * a.R), dim3(1024), lds, st, a);
+  return MI355_OK;
+}
+// number of grid-barrier spins that gave up since the library was loaded (0 unless a block never became resident); synchronises
+extern "C" int mi355_bn_resident_timeouts(unsigned* out) {
+  unsigned v[4] = {0, 0, 0, 0};
+  if (!out) MI_FAIL(MI355_EINVAL, "bn_resident_timeouts: out is null");
+  if (hipMemcpyFromSymbol(v, HIP_SYMBOL(bn_res_sync), sizeof(v)) != hipSuccess) MI_FAIL(MI355_ELAUNCH, "bn_resident_timeouts: copy failed");
+  *out = v[0];
+  return MI355_OK;
+}
+
 static void launch_bwd_apply(int dtype, int relu, dim3 ga, hipStream_t st, const void* dy, const void* x, const void* y, const float* save_mean,
                              const float* save_invstd, const float* coeff, const float* beta, void* dx, void* dresidual, long rows, int C,
                              int TX, const unsigned char* mk, void* q8_out, float* q8_state) {
@@ -557,6 +771,19 @@ extern "C" int mi355_bn_bwd(const void* dy, const void* x, const void* y, const 
   if (relu) relu = mk ? 3 : (y ? 1 : 2);
   if (relu == 2 && !beta) MI_FAIL(MI355_EINVAL, "bn_bwd: relu without y needs beta");
   hipStream_t st = as_stream(stream);
+  BnResPlan rp;
+  if (relu != 1 && !q8_out && bn_resident_plan(rows, C, CH, &rp)) {
+    BnResArgs a;
+    a.dy = dy; a.x = x; a.mean = save_mean; a.invstd = save_invstd; a.gamma = gamma; a.beta = beta; a.dx = dx; a.dres = dresidual;
+    a.dgamma = dgamma; a.dbeta = dbeta; a.mask = mk; a.partial = reinterpret_cast<float*>(ws); a.rows = rows; a.C = C;
+    a.G = rp.G; a.R = rp.R; a.rpb = rp.rpb; a.accumulate = accumulate; a.inv_rows = 1.0f / (float)rows;
+    int e;
+    if (dtype == MI355_BF16) e = relu == 0 ? bn_resident_launch<bf16_t, 0>(a, rp.lds, st) : relu == 2 ? bn_resident_launch<bf16_t, 2>(a, rp.lds, st) : bn_resident_launch<bf16_t, 3>(a, rp.lds, st);
+    else e = relu == 0 ? bn_resident_launch<float, 0>(a, rp.lds, st) : relu == 2 ? bn_resident_launch<float, 2>(a, rp.lds, st) : bn_resident_launch<float, 3>(a, rp.lds, st);
+    if (e) return e;
+    MI_CHECK_LAUNCH("bn_bwd (resident)");
+    return MI355_OK;
+  }
   BnPlan p = bn_plan(rows, C, CH, bwd_slices());
   float* partial = reinterpret_cast<float*>(ws);
   float* coeff = partial + (size_t)p.nslices * C * 3;   // 3*C floats (4*C reserved)

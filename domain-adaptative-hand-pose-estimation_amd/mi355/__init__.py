@@ -71,6 +71,7 @@ SIGNATURES = {
     'mi355_bn_eval_fwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _L, _I, _F, _I, _I, _P]),
     'mi355_bn_bwd_partials': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _L, _I, _I, _I, _P, _I, _P, _P, _P, _P, _P]),
     'mi355_bn_bwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _L, _I, _I, _I, _P, _Z, _P, _P, _P, _P]),
+    'mi355_bn_resident_timeouts': (_I, [_P]),
     'mi355_maxpool_fwd': (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
     'mi355_maxpool_bwd': (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
     'mi355_nchw_to_nhwc': (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),

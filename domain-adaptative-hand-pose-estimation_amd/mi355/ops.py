@@ -337,6 +337,13 @@ def bn_bwd(dy, x, y, gamma, mean, invstd, dgamma, dbeta, accumulate, relu, want_
 
 
 # ---------------------------------------------------------------- max pool
+def bn_resident_timeouts():
+    """Grid-barrier spins of the one-launch BatchNorm backward that gave up since the library was loaded (0 = healthy)."""
+    n = ctypes.c_uint(0)
+    call('mi355_bn_resident_timeouts', ctypes.byref(n))
+    return n.value
+
+
 def maxpool_fwd(x):
     N, C, H, W = x.shape
     Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1

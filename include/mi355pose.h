@@ -190,6 +190,12 @@ int mi355_bn_bwd(const void* dy, const void* x, const void* y, const float* gamm
                  const float* save_mean, const float* save_invstd, void* dx, void* dresidual, float* dgamma, float* dbeta,
                  int accumulate, long rows, int C, int relu, int dtype, void* ws, size_t ws_bytes,
                  const void* relu_mask, void* q8_out, float* q8_state, void* stream);
+/* mi355_bn_bwd takes ONE launch when x and dy fit the chip's LDS together (<= ~16.8 MB each on 256 CUs), C is a multiple of
+ * 64 (bf16) / 32 (fp32) and the mask does not come from y: each CU keeps its tile of both tensors in LDS between the
+ * reduction and the apply pass (3 tensor passes over HBM instead of 5); the blocks exchange their partial sums inside the
+ * launch behind a bounded spin.  MI355_BN_RESIDENT=0 keeps the three-launch form.  *out = spins that gave up since the
+ * library was loaded (0 unless a block could not become resident; the results of such a launch are invalid). Synchronises. */
+int mi355_bn_resident_timeouts(unsigned* out);
 
 /* ---------------------------------------------------------------- stem max-pool 3x3 s2 p1
  * Replaces nn.MaxPool2d(3,2,1) of the torchvision stem (uda/model/resnet.py:28).  argidx: uint8 window

@@ -223,7 +223,11 @@ def test_bn_train_fwd_bwd(gpu, dt, shape, relu, res):
         dg2 = torch.zeros(C, device=gpu); db2 = torch.zeros(C, device=gpu)
         dx2, dres2 = ops.bn_bwd(_nhwc(dy, dt, gpu), xd, None, gamma.to(gpu), mean, invstd, dg2, db2, False, relu, res,
                                 beta=beta.to(gpu), relu_mask=mask)
-        assert torch.equal(dx2, dx) and torch.equal(dres2, dres) and torch.equal(dg2, dg) and torch.equal(db2, db)
+        # (mask-from-y runs as reduce + finalize + apply, the bit-mask form may take the one-launch LDS-resident kernel:
+        #  same masked gradient bit for bit, sums folded in another order)
+        assert torch.equal(dres2, dres)
+        assert float((dx2.float() - dx.float()).abs().max()) <= (2e-2 if dt == 'bf16' else 1e-5) * (float(dx.float().abs().max()) + 1)
+        assert torch.allclose(dg2, dg, rtol=1e-4, atol=1e-4) and torch.allclose(db2, db, rtol=1e-4, atol=1e-4)
     # eval mode
     ye = ops.bn_eval_fwd(xd, rd, gamma.to(gpu), beta.to(gpu), rm.to(gpu), rv.to(gpu), 1e-5, relu)
     ye_ref = F.batch_norm(x, rm, rv, gamma, beta, False, 0.1, 1e-5)
@@ -232,6 +236,51 @@ def test_bn_train_fwd_bwd(gpu, dt, shape, relu, res):
     if relu:
         ye_ref = F.relu(ye_ref)
     assert float((_back(ye) - ye_ref).abs().max()) <= _tol(dt, ye_ref)
+
+
+@pytest.mark.parametrize('dt', ['f32', 'bf16'])
+@pytest.mark.parametrize('shape', [(64, 256, 16, 16), (64, 2048, 8, 8), (64, 128, 32, 32), (5, 192, 7, 9), (64, 512, 8, 8), (1, 64, 1, 3)])
+@pytest.mark.parametrize('mode', ['plain', 'relu', 'relu_residual'])
+def test_bn_backward_one_launch_lds_resident(gpu, dt, shape, mode):
+    """Tensors that fit the chip's LDS take the one-launch backward (csrc/bn.hip bn_bwd_resident_kernel): model-sized and
+    ragged shapes, all three mask sources it covers, against torch's fp32 batch_norm backward on the same rounded operands;
+    gradient accumulation into dgamma / dbeta; no grid-barrier spin gave up."""
+    ops = _ops()
+    N, C, H, W = shape
+    relu, res = mode != 'plain', mode == 'relu_residual'
+    tdt = torch.bfloat16 if dt == 'bf16' else torch.float32
+    g = torch.Generator(device='cpu').manual_seed(1234 + C + H)
+    x = (torch.randn(shape, generator=g) * 1.5 + 0.3).to(tdt).float().to(gpu)
+    dy = torch.randn(shape, generator=g).to(tdt).float().to(gpu)
+    r = torch.randn(shape, generator=g).to(tdt).float().to(gpu) if res else None
+    gamma = (1 + 0.1 * torch.randn(C, generator=g)).to(gpu); beta = (0.1 * torch.randn(C, generator=g)).to(gpu)
+    xr = x.clone().requires_grad_(True); gr = gamma.clone().requires_grad_(True); br = beta.clone().requires_grad_(True)
+    rr = r.clone().requires_grad_(True) if res else None
+    y_ref = F.batch_norm(xr, None, None, gr, br, True, 0.1, 1e-5)
+    if res:
+        y_ref = y_ref + rr
+    if relu:
+        y_ref = F.relu(y_ref)
+    y_ref.backward(dy)
+    to = lambda t: t.to(tdt).contiguous(memory_format=torch.channels_last)
+    xd, dyd = to(x), to(dy)
+    rm, rv, nbt = torch.zeros(C, device=gpu), torch.ones(C, device=gpu), torch.zeros((), dtype=torch.int64, device=gpu)
+    mask = ops.bn_relu_mask(xd) if res else None
+    y, mean, invstd = ops.bn_train_fwd(xd, to(r) if res else None, gamma, beta, rm, rv, nbt, 1e-5, 0.1, relu, relu_mask=mask)
+    dg = torch.full((C,), 0.5, device=gpu); db = torch.full((C,), -0.25, device=gpu)
+    dx, dres = ops.bn_bwd(dyd, xd, None, gamma, mean, invstd, dg, db, True, relu, res, beta=beta, relu_mask=mask)
+    scale = float(xr.grad.abs().max()) + 1e-6
+    # fp32: the forward's y = x*sc+sh may round a value next to zero to the other side of the ReLU than torch's formula does
+    err = (dx.float() - xr.grad).abs()
+    tol = (2e-2 if dt == 'bf16' else 2e-4) * scale
+    assert float((err > tol).float().mean()) <= (1e-4 if relu else 0.0), float(err.max())
+    if res:
+        assert float(((dres.float() - rr.grad).abs() > 1e-6).float().mean()) <= 1e-4
+    gt = 4e-3 * (8 if dt == 'bf16' else 1)
+    flips = 2 if relu else 0       # a ReLU decision that flips on one element moves that channel's sums by |dy|, |dy * xhat|
+    assert int(((dg - 0.5 - gr.grad).abs() > gt * (float(gr.grad.abs().max()) + 1)).sum()) <= flips
+    assert int(((db + 0.25 - br.grad).abs() > gt * (float(br.grad.abs().max()) + 1)).sum()) <= flips
+    assert ops.bn_resident_timeouts() == 0
 
 
 @pytest.mark.parametrize('dt', ['f32', 'bf16'])
