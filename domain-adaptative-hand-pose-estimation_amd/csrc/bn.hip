@@ -442,12 +442,14 @@ struct BnResArgs {
   const void* dy; const void* x; const float* mean; const float* invstd; const float* gamma; const float* beta;
   void* dx; void* dres; float* dgamma; float* dbeta; const unsigned char* mask;
   float* partial;                       // [G][R][2 * channels per group]
-  long rows; int C, G, R, rpb, accumulate; float inv_rows;
+  long rows; int C, G, R, rpb, keep, accumulate; float inv_rows;      // keep: rows of a block's tile that stay in LDS
 };
 // One arrival counter per grid size, never reset: a launch of n blocks moves it from one multiple of n to the next, so a
 // block that drew ticket v waits for the counter to reach (v / n + 1) * n (wrap-safe compare).  Launches of this kernel on
 // one device must not overlap in time (this library issues them on one stream; MI355_BN_RESIDENT=0 otherwise).
 #define BN_RES_MAXBLK 1024
+#define BN_RES_KR 0        // tile rows per thread held in registers (8 VGPRs each)
+#define BN_RES_NT 1024     // threads per block
 __device__ unsigned bn_res_sync[BN_RES_MAXBLK + 4];     // [n] arrivals of the n-block launches; [0]: spins that gave up
 
 __device__ __forceinline__ void bn_res_grid_barrier(unsigned nblk, int t) {
@@ -471,18 +473,23 @@ __device__ __forceinline__ void bn_res_grid_barrier(unsigned nblk, int t) {
   __syncthreads();
 }
 
-template <typename T, int RELU>
-__global__ __launch_bounds__(1024) void bn_bwd_resident_kernel(BnResArgs p) {
-  constexpr int CH = Chunk<T>::N, GC = 8 * CH, NT = 1024, RL = NT / 8, NW = NT / 64, NL = NT / (GC * 2);
+// A block's tile, by row: the first KR * NT / 8 rows live in REGISTERS (row ty + k NT / 8 in slot k of its thread), the
+// next `keep` rows in LDS, the rest is streamed from HBM in both passes.  Built with KR = 0, NT = 1024: 512 threads with
+// 8 register rows each (the register file holds more than the LDS) measured slower on every size but one -- two waves per
+// SIMD hide less latency than the extra residency saves (64x64x64x64 bf16: 36.1 vs 31.0 us; 64x1024x16x16: 32.6 vs 28.5).
+template <typename T, int RELU, int KR, int NT>
+__global__ __launch_bounds__(NT) void bn_bwd_resident_kernel(BnResArgs p) {
+  constexpr int CH = Chunk<T>::N, GC = 8 * CH, RL = NT / 8, NW = NT / 64, NL = NT / (GC * 2), RR = KR * RL;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int t = threadIdx.x, tx = t & 7, ty = t >> 3, lane = t & 63, wave = t >> 6;
   const int g = blockIdx.x % p.G, r = blockIdx.x / p.G;
   const long row0 = (long)r * p.rpb;
   long row1 = row0 + p.rpb; if (row1 > p.rows) row1 = p.rows;
   const int nrows = row1 > row0 ? (int)(row1 - row0) : 0;
+  const int keep = p.keep;
   uint4* xs = reinterpret_cast<uint4*>(smem);
-  uint4* ds = xs + (size_t)p.rpb * 8;
-  float* red = reinterpret_cast<float*>(ds + (size_t)p.rpb * 8);     // [NW][GC][2], later [NL][GC*2]
+  uint4* ds = xs + (size_t)keep * 8;
+  float* red = reinterpret_cast<float*>(ds + (size_t)keep * 8);      // [NW][GC][2], later [NL][GC*2]
   float* tot = red + NW * GC * 2;                                    // [GC*2]
   const T* __restrict__ X = reinterpret_cast<const T*>(p.x);
   const T* __restrict__ DY = reinterpret_cast<const T*>(p.dy);
@@ -494,30 +501,49 @@ __global__ __launch_bounds__(1024) void bn_bwd_resident_kernel(BnResArgs p) {
     sc[e] = p.gamma[c0 + e] * is[e];                                  // forward scale (bn_finalize_kernel)
     sft[e] = (RELU == 2) ? p.beta[c0 + e] - mu[e] * sc[e] : 0.f;
   }
-  // ---- pass 1: HBM -> LDS, per-thread sums over its rows (four rows in flight per thread)
-  for (int base = ty; base < nrows; base += 4 * RL) {
+  auto mask_of = [&](int lr) -> unsigned { return (RELU == 3) ? (unsigned)p.mask[(size_t)(row0 + lr) * cpr + chunk] : 0u; };
+  auto fold = [&](const uint4& qxv, const uint4& qdv, unsigned mb) {
+    float v[CH], gq[CH]; Chunk<T>::unpack(qxv, v); Chunk<T>::unpack(qdv, gq);
+#pragma unroll
+    for (int e = 0; e < CH; ++e) {
+      if (RELU == 2) gq[e] = (v[e] * sc[e] + sft[e]) > 0.f ? gq[e] : 0.f;
+      if (RELU == 3) gq[e] = ((mb >> e) & 1u) ? gq[e] : 0.f;
+      s1[e] += gq[e]; s2[e] += gq[e] * ((v[e] - mu[e]) * is[e]);
+    }
+  };
+  // ---- pass 1: HBM -> registers / LDS, per-thread sums over its rows
+  uint4 rx[KR > 0 ? KR : 1], rd[KR > 0 ? KR : 1];
+  {
+    unsigned mk[KR > 0 ? KR : 1];
+#pragma unroll
+    for (int k = 0; k < KR; ++k) {
+      const int lr = ty + k * RL;
+      rx[k] = make_uint4(0, 0, 0, 0); rd[k] = make_uint4(0, 0, 0, 0); mk[k] = 0;
+      if (lr < nrows) {
+        const size_t off = (size_t)(row0 + lr) * C + c0;
+        rx[k] = *reinterpret_cast<const uint4*>(X + off); rd[k] = *reinterpret_cast<const uint4*>(DY + off); mk[k] = mask_of(lr);
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < KR; ++k)
+      if (ty + k * RL < nrows) fold(rx[k], rd[k], mk[k]);
+  }
+  for (int base = RR + ty; base < nrows; base += 4 * RL) {          // four rows in flight per thread
     uint4 qx[4], qd[4]; unsigned mk[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const int lr = base + k * RL;
       if (lr < nrows) {
         const size_t off = (size_t)(row0 + lr) * C + c0;
-        qx[k] = *reinterpret_cast<const uint4*>(X + off); qd[k] = *reinterpret_cast<const uint4*>(DY + off);
-        mk[k] = (RELU == 3) ? (unsigned)p.mask[(size_t)(row0 + lr) * cpr + chunk] : 0u;
+        qx[k] = *reinterpret_cast<const uint4*>(X + off); qd[k] = *reinterpret_cast<const uint4*>(DY + off); mk[k] = mask_of(lr);
       }
     }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      const int lr = base + k * RL;
+      const int lr = base + k * RL, li = lr - RR;
       if (lr < nrows) {
-        xs[lr * 8 + tx] = qx[k]; ds[lr * 8 + tx] = qd[k];
-        float v[CH], gq[CH]; Chunk<T>::unpack(qx[k], v); Chunk<T>::unpack(qd[k], gq);
-#pragma unroll
-        for (int e = 0; e < CH; ++e) {
-          if (RELU == 2) gq[e] = (v[e] * sc[e] + sft[e]) > 0.f ? gq[e] : 0.f;
-          if (RELU == 3) gq[e] = ((mk[k] >> e) & 1u) ? gq[e] : 0.f;
-          s1[e] += gq[e]; s2[e] += gq[e] * ((v[e] - mu[e]) * is[e]);
-        }
+        if (li < keep) { xs[li * 8 + tx] = qx[k]; ds[li * 8 + tx] = qd[k]; }
+        fold(qx[k], qd[k], mk[k]);
       }
     }
   }
@@ -576,13 +602,13 @@ __global__ __launch_bounds__(1024) void bn_bwd_resident_kernel(BnResArgs p) {
       if (p.dgamma) p.dgamma[c0 + e] = (p.accumulate ? p.dgamma[c0 + e] : 0.f) + s2[e];
     }
   }
-  // ---- pass 2: LDS -> dx (and the masked dy for the residual branch)
+  // ---- pass 2: register rows, LDS rows, then the rest of the tile streamed from HBM again -> dx (and the masked dy for
+  // the residual branch)
   T* __restrict__ DX = reinterpret_cast<T*>(p.dx);
   T* __restrict__ DR = reinterpret_cast<T*>(p.dres);
-  for (int lr = ty; lr < nrows; lr += RL) {
+  auto finish = [&](int lr, const uint4& qxv, const uint4& qdv, unsigned mb) {
     const size_t off = (size_t)(row0 + lr) * C + c0;
-    float v[CH], gq[CH]; Chunk<T>::unpack(xs[lr * 8 + tx], v); Chunk<T>::unpack(ds[lr * 8 + tx], gq);
-    const unsigned mb = (RELU == 3) ? (unsigned)p.mask[(size_t)(row0 + lr) * cpr + chunk] : 0u;
+    float v[CH], gq[CH]; Chunk<T>::unpack(qxv, v); Chunk<T>::unpack(qdv, gq);
 #pragma unroll
     for (int e = 0; e < CH; ++e) {
       if (RELU == 2) gq[e] = (v[e] * sc[e] + sft[e]) > 0.f ? gq[e] : 0.f;
@@ -592,6 +618,29 @@ __global__ __launch_bounds__(1024) void bn_bwd_resident_kernel(BnResArgs p) {
 #pragma unroll
     for (int e = 0; e < CH; ++e) v[e] = sc[e] * (gq[e] - k1[e] - (v[e] - mu[e]) * is[e] * k2[e]);
     Chunk<T>::store(DX + off, v);
+  };
+#pragma unroll
+  for (int k = 0; k < KR; ++k) {
+    const int lr = ty + k * RL;
+    if (lr < nrows) finish(lr, rx[k], rd[k], mask_of(lr));
+  }
+  const int nlds = nrows - RR < keep ? nrows - RR : keep;
+  for (int li = ty; li < nlds; li += RL) finish(RR + li, xs[li * 8 + tx], ds[li * 8 + tx], mask_of(RR + li));
+  for (int base = RR + keep + ty; base < nrows; base += 4 * RL) {
+    uint4 qx[4], qd[4]; unsigned mk[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int lr = base + k * RL;
+      if (lr < nrows) {
+        const size_t off = (size_t)(row0 + lr) * C + c0;
+        qx[k] = *reinterpret_cast<const uint4*>(X + off); qd[k] = *reinterpret_cast<const uint4*>(DY + off); mk[k] = mask_of(lr);
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int lr = base + k * RL;
+      if (lr < nrows) finish(lr, qx[k], qd[k], mk[k]);
+    }
   }
 }
 
@@ -700,7 +749,7 @@ extern "C" int mi355_bn_eval_fwd(const void* x, const void* residual, void* y, c
 }
 
 // ---- resident backward: plan + launch (returns false when the tensor does not fit / the mode is not covered)
-struct BnResPlan { int G, R, rpb; size_t lds; };
+struct BnResPlan { int G, R, rpb, keep; size_t lds; };
 static bool bn_resident_plan(long rows, int C, int CH, BnResPlan* q) {
   static const bool on = !(getenv("MI355_BN_RESIDENT") && atoi(getenv("MI355_BN_RESIDENT")) == 0);
   if (!on) return false;
@@ -722,19 +771,27 @@ static bool bn_resident_plan(long rows, int C, int CH, BnResPlan* q) {
   long R = ncu / q->G; if (R > rows) R = rows;
   q->rpb = (int)((rows + R - 1) / R);
   q->R = (int)((rows + q->rpb - 1) / q->rpb);
-  q->lds = (size_t)q->rpb * 8 * 16 * 2 + (size_t)(16 * GC * 2 + GC * 2) * sizeof(float);
-  return q->lds <= max_lds && (size_t)q->G * q->R <= (size_t)ncu && q->G * q->R <= BN_RES_MAXBLK;
+  static const long max_bytes = getenv("MI355_BN_RESIDENT_MAX") ? atol(getenv("MI355_BN_RESIDENT_MAX")) : (1L << 62);
+  if (rows * C * (16 / CH) > max_bytes) return false;
+  const size_t scratch = (size_t)(BN_RES_NT / 64 * GC * 2 + GC * 2) * sizeof(float);
+  long keep = (long)((max_lds - scratch) / 256);        // tile rows (128 B of x + 128 B of dy each) that fit beside the scratch
+  const long reg_rows = (long)BN_RES_KR * (BN_RES_NT / 8);
+  const long rest = q->rpb > reg_rows ? q->rpb - reg_rows : 0;
+  if (keep > rest) keep = rest;
+  q->keep = (int)keep;
+  q->lds = (size_t)keep * 256 + scratch;
+  return (size_t)q->G * q->R <= (size_t)ncu && q->G * q->R <= BN_RES_MAXBLK;
 }
 template <typename T, int RELU>
 static int bn_resident_launch(const BnResArgs& a, size_t lds, hipStream_t st) {
   static size_t raised = 0;
-  auto kern = bn_bwd_resident_kernel<T, RELU>;
+  auto kern = bn_bwd_resident_kernel<T, RELU, BN_RES_KR, BN_RES_NT>;
   if (lds > raised) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
       MI_FAIL(MI355_ELAUNCH, "bn_bwd: cannot raise the dynamic LDS limit to %zu bytes", lds);
     raised = lds;
   }
-  hipLaunchKernelGGL(kern, dim3(a.G * a.R), dim3(1024), lds, st, a);
+  hipLaunchKernelGGL(kern, dim3(a.G * a.R), dim3(BN_RES_NT), lds, st, a);
   return MI355_OK;
 }
 // number of grid-barrier spins that gave up since the library was loaded (0 unless a block never became resident); synchronises
@@ -776,7 +833,7 @@ extern "C" int mi355_bn_bwd(const void* dy, const void* x, const void* y, const 
     BnResArgs a;
     a.dy = dy; a.x = x; a.mean = save_mean; a.invstd = save_invstd; a.gamma = gamma; a.beta = beta; a.dx = dx; a.dres = dresidual;
     a.dgamma = dgamma; a.dbeta = dbeta; a.mask = mk; a.partial = reinterpret_cast<float*>(ws); a.rows = rows; a.C = C;
-    a.G = rp.G; a.R = rp.R; a.rpb = rp.rpb; a.accumulate = accumulate; a.inv_rows = 1.0f / (float)rows;
+    a.G = rp.G; a.R = rp.R; a.rpb = rp.rpb; a.keep = rp.keep; a.accumulate = accumulate; a.inv_rows = 1.0f / (float)rows;
     int e;
     if (dtype == MI355_BF16) e = relu == 0 ? bn_resident_launch<bf16_t, 0>(a, rp.lds, st) : relu == 2 ? bn_resident_launch<bf16_t, 2>(a, rp.lds, st) : bn_resident_launch<bf16_t, 3>(a, rp.lds, st);
     else e = relu == 0 ? bn_resident_launch<float, 0>(a, rp.lds, st) : relu == 2 ? bn_resident_launch<float, 2>(a, rp.lds, st) : bn_resident_launch<float, 3>(a, rp.lds, st);
