@@ -644,6 +644,20 @@ __global__ __launch_bounds__(NT) void bn_bwd_resident_kernel(BnResArgs p) {
   }
 }
 
+// g <- bit of mask set ? g : 0, in place (the stand-alone form of the masking the consumers of a residual block's fork
+// gradient normally do on the fly: mi355_conv_dgrad_masked_acc, mi355_bn_bwd with relu_mask)
+template <typename T>
+__global__ __launch_bounds__(256) void apply_relu_mask_kernel(T* __restrict__ g, const unsigned char* __restrict__ mask, size_t nchunks) {
+  constexpr int CH = Chunk<T>::N;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nchunks; i += (size_t)gridDim.x * 256) {
+    float v[CH]; Chunk<T>::load(g + i * CH, v);
+    const unsigned mb = mask[i];
+#pragma unroll
+    for (int e = 0; e < CH; ++e) v[e] = ((mb >> e) & 1u) ? v[e] : 0.f;
+    Chunk<T>::store(g + i * CH, v);
+  }
+}
+
 __global__ __launch_bounds__(256) void colsum_finalize_kernel(const float* __restrict__ partial, int nslices, int C, float* out, int accumulate) {
   const int lane = threadIdx.x & 63;
   const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -876,6 +890,17 @@ extern "C" int mi355_bn_bwd_partials(const void* dy, const void* x, const void* 
   if (int e = q8_check(q8_out, q8_state, dtype, C)) return e;
   launch_bwd_apply(dtype, relu, ga, st, dy, x, y, save_mean, save_invstd, coeff, beta, dx, dresidual, rows, C, p.TX, mk, q8_out, q8_state);
   MI_CHECK_LAUNCH("bn_bwd_partials");
+  return MI355_OK;
+}
+
+extern "C" int mi355_apply_relu_mask(void* g, const void* relu_mask, long rows, int C, int dtype, void* stream) {
+  int CH; if (int e = bn_check(rows, C, dtype, &CH)) return e;
+  if (!g || !relu_mask) MI_FAIL(MI355_EINVAL, "apply_relu_mask: null pointer");
+  const size_t nchunks = (size_t)rows * (C / CH);
+  long grid = (long)((nchunks + 255) / 256); if (grid > 4096) grid = 4096;
+  if (dtype == MI355_BF16) hipLaunchKernelGGL(apply_relu_mask_kernel<bf16_t>, dim3((unsigned)grid), dim3(256), 0, as_stream(stream), (bf16_t*)g, (const unsigned char*)relu_mask, nchunks);
+  else hipLaunchKernelGGL(apply_relu_mask_kernel<float>, dim3((unsigned)grid), dim3(256), 0, as_stream(stream), (float*)g, (const unsigned char*)relu_mask, nchunks);
+  MI_CHECK_LAUNCH("apply_relu_mask");
   return MI355_OK;
 }
 

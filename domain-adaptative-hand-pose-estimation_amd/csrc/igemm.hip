@@ -401,7 +401,13 @@ __global__ __launch_bounds__(64 * WGM * WGN, (KW3 && BM == 256) ? 2 : 1) void ga
       if (R) { float w[CH]; Chunk<T>::load(R + g, w);
 #pragma unroll
         for (int e = 0; e < CH; ++e) v[e] += w[e]; }
-      if (p.accumulate) { float w[CH]; Chunk<T>::load(D + g, w);
+      if (p.accumulate) {
+        // the optional bit mask is applied to the packed words BEFORE unpacking: selecting per unpacked float made the
+        // compiler permute the registers and feed v_pk_add_f32 through op_sel, and those adds dropped an addend now and
+        // then (lanes 48-63 only, run-to-run different: 40 - 240 of 8.4 M elements on the 32x64x64x64 dgrad) on gfx950
+        uint4 q = *reinterpret_cast<const uint4*>(D + g);
+        if (p.acc_mask) q = keep_masked<T>(q, p.acc_mask[g / CH]);
+        float w[CH]; Chunk<T>::unpack(q, w);
 #pragma unroll
         for (int e = 0; e < CH; ++e) v[e] += w[e]; }
       Chunk<T>::store(D + g, v);
@@ -1332,7 +1338,7 @@ extern "C" int mi355_conv1x1_heatmap(const void* x, const void* w, const float* 
 // decomposed into stride^2 phases (iy%s, ix%s), each a unit-stride gather over its own tap subset.
 static int conv_dgrad_impl(const mi355_conv_desc* d, const void* dy, const void* wT, const float* bias, const float* scale_dev,
                            int accumulate, void* dx, float* partial, size_t partial_bytes, int* nslices, void* stream,
-                           const mi355_bn_bwd_src* bn = nullptr, const Fp8Extra* f8 = nullptr);
+                           const mi355_bn_bwd_src* bn = nullptr, const Fp8Extra* f8 = nullptr, const void* acc_mask = nullptr);
 extern "C" int mi355_conv_dgrad_fp8(const mi355_conv_desc* d, const void* dy8, int dy_fmt, const void* wT8, const float* descale_dy,
                                     const float* descale_w, const float* scale_dev, int accumulate, void* dx, float* partial,
                                     size_t partial_bytes, int* nslices, void* stream) {
@@ -1351,6 +1357,13 @@ extern "C" int mi355_conv_dgrad(const mi355_conv_desc* d, const void* dy, const 
                                 const float* scale_dev, int accumulate, void* dx, void* stream) {
   return conv_dgrad_impl(d, dy, wT, bias, scale_dev, accumulate, dx, nullptr, 0, nullptr, stream);
 }
+// dx <- dgrad + (bit of acc_mask set ? dx : 0): the fork of a residual block whose other branch's gradient is still the
+// UNMASKED dy of the block's final ReLU -- BatchNorm's backward then need not write the masked copy (mi355_bn_bwd dresidual)
+extern "C" int mi355_conv_dgrad_masked_acc(const mi355_conv_desc* d, const void* dy, const void* wT, const float* scale_dev, void* dx,
+                                           const void* acc_mask, void* stream) {
+  if (!acc_mask) MI_FAIL(MI355_EINVAL, "conv_dgrad_masked_acc: acc_mask is null");
+  return conv_dgrad_impl(d, dy, wT, nullptr, scale_dev, 1, dx, nullptr, 0, nullptr, stream, nullptr, nullptr, acc_mask);
+}
 // ConvTranspose2d forward (= conv-form dgrad) with the BatchNorm statistics of its output fused into the epilogue
 extern "C" int mi355_conv_dgrad_stats(const mi355_conv_desc* d, const void* dy, const void* wT, void* dx, float* partial,
                                       size_t partial_bytes, int* nslices, void* stream) {
@@ -1359,8 +1372,9 @@ extern "C" int mi355_conv_dgrad_stats(const mi355_conv_desc* d, const void* dy, 
 }
 static int conv_dgrad_impl(const mi355_conv_desc* d, const void* dy, const void* wT, const float* bias, const float* scale_dev,
                            int accumulate, void* dx, float* partial, size_t partial_bytes, int* nslices, void* stream,
-                           const mi355_bn_bwd_src* bn, const Fp8Extra* f8) {
+                           const mi355_bn_bwd_src* bn, const Fp8Extra* f8, const void* acc_mask) {
   if (nslices) *nslices = 0;
+  if (acc_mask && (!accumulate || bn || f8)) MI_FAIL(MI355_EINVAL, "conv_dgrad: acc_mask goes with accumulate = 1 on the plain bf16 / fp32 path only");
   if (int e = check_desc(d)) return e;
   if ((d->dtype == MI355_FP8) != (f8 != nullptr)) MI_FAIL(MI355_EINVAL, "fp8 descriptors go through the *_fp8 entry points (and only they)");
   if (f8 && bn) MI_FAIL(MI355_EINVAL, "fp8 dgrad: no BatchNorm-backward epilogue");
@@ -1388,6 +1402,7 @@ static int conv_dgrad_impl(const mi355_conv_desc* d, const void* dy, const void*
   a.in_sy = a.in_sx = 1; a.Ho = d->Hi; a.Wo = d->Wi; a.out_sy = a.out_sx = s;
   a.Nout = d->Ci; a.ldd = d->Ci; a.ldb = d->kh * d->kw * d->Co;
   a.accumulate = accumulate ? 1 : 0;
+  a.acc_mask = reinterpret_cast<const unsigned char*>(acc_mask);
   int nt = 0;
   for (int py = 0; py < s; ++py)
     for (int px = 0; px < s; ++px) {

@@ -38,7 +38,24 @@ struct GatherArgs {
   const float* scale2;         // fp8 path: further device scalars multiplied into the output (operand descales)
   const float* scale3;
   int a_fmt;                   // fp8 path: format of the gathered operand, 0 = e4m3, 1 = e5m2
+  // accumulate = 1 only: the value already in D is kept where its bit is set ([rows][ldd / chunk] bytes, bit e = channel
+  // chunk * chunk_size + e: the ReLU bit mask of BatchNorm's forward) -- D + this launch's result = masked fork gradient
+  const unsigned char* acc_mask;
 };
+
+// 16-byte chunk with the elements whose mask bit is clear set to zero (bit e = element e; bf16: two elements per word)
+template <typename T> __device__ __forceinline__ uint4 keep_masked(uint4 q, unsigned mb) {
+  unsigned w[4] = {q.x, q.y, q.z, q.w};
+  if constexpr (sizeof(T) == 2) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      w[i] &= ((0u - ((mb >> (2 * i)) & 1u)) & 0x0000ffffu) | ((0u - ((mb >> (2 * i + 1)) & 1u)) & 0xffff0000u);
+  } else {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) w[i] &= 0u - ((mb >> i) & 1u);
+  }
+  return make_uint4(w[0], w[1], w[2], w[3]);
+}
 
 // swizzled byte offset of 16-byte chunk `c` (0..7) in 128-byte row `r`
 __device__ __forceinline__ int swz128(int r, int c) { return r * 128 + ((c ^ ((r >> 1) & 7)) << 4); }

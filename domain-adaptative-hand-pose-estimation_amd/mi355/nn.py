@@ -8,6 +8,7 @@ nn.ConvTranspose2d / nn.BatchNorm2d children) but
     (first write after `zero_grad` overwrites, later ones accumulate), not returned through autograd.
 """
 import math
+import os as _os
 
 import torch
 import torch.nn as nn
@@ -37,6 +38,7 @@ def mark_grads_fresh(params):
         if p.grad is not None:
             p._mi_fresh = True
     _BWD_PARTIALS.clear()          # leftovers of a backward pass that never reached their BatchNorm
+    _LAZY_MASK.clear()
     _GRAD_Q8.clear()               # ... or whose fp8 gradient copy no conv picked up
 
 
@@ -55,7 +57,29 @@ def _as_feature(x, dtype):
     return x.to(dtype).contiguous(memory_format=torch.channels_last)   # foreign layout: torch as glue
 
 
+# Gradients that still lack a ReLU mask: data_ptr -> (tensor, bit mask).  The last BatchNorm of a residual block hands its
+# incoming dy on to the identity branch UNMASKED (no `dresidual` write) with the forward's bit mask registered here; the
+# branch's consumer -- conv1's dgrad epilogue (_ConvSkipFn) or the downsample BatchNorm's backward -- applies the mask on the
+# fly.  Every other consumer goes through _as_grad, which applies it in place first.  The entry keeps the tensor alive.
+_LAZY_MASK = {}
+_LAZY_RES = _os.environ.get('MI355_BN_LAZY_DRES', '1') == '1'      # A/B switch
+
+
+def _take_lazy(g):
+    """The pending bit mask of gradient tensor g (None when g is an ordinary gradient); the entry is removed."""
+    if not _LAZY_MASK or g is None:
+        return None
+    ent = _LAZY_MASK.get(g.data_ptr())
+    if ent is None or ent[0] is not g:
+        return None
+    del _LAZY_MASK[g.data_ptr()]
+    return ent[1]
+
+
 def _as_grad(dy, dtype):
+    mask = _take_lazy(dy)
+    if mask is not None:
+        ops.apply_relu_mask(dy, mask)
     if ops.is_nhwc(dy) and dy.dtype == dtype:
         return dy
     return dy.to(dtype).contiguous(memory_format=torch.channels_last)
@@ -218,7 +242,6 @@ def _chk_convform(weight):
 
 
 # ---------------------------------------------------------------- autograd functions
-import os as _os
 _FUSE_STATS = _os.environ.get('MI355_BN_STATS_FUSE', '1') == '1'      # A/B switch: BN statistics in the conv epilogue
 _FUSE_BNBWD = _os.environ.get('MI355_BN_BWD_FUSE', '0') == '1'        # opt-in: BN backward reduction in the dgrad epilogue (measured neutral)
 _SKIP_FUSE = _os.environ.get('MI355_SKIP_FUSE', '1') == '1'             # A/B switch: residual-fork gradient add inside dgrad
@@ -307,8 +330,14 @@ def _conv_forward(ctx, mod, x, bias, residual, stats_ok=True):
     return y
 
 
-def _conv_dgrad(ctx, x, dy, scale_dev=None, out=None, accumulate=False):
+def _conv_dgrad(ctx, x, dy, scale_dev=None, out=None, accumulate=False, acc_mask=None):
     mod = ctx.mod
+    if acc_mask is not None:
+        if ctx.fp8 or ctx.bn_src is not None or not accumulate:
+            ops.apply_relu_mask(out, acc_mask)          # (paths without the masked epilogue: mask first, then accumulate)
+        else:
+            _, _, wt = mod._plan(x)
+            return ops.conv_dgrad_masked_acc(ctx.desc, dy, wt, out, acc_mask, scale_dev=scale_dev)
     if ctx.fp8:
         _, _, _, wt8, sw = mod._plan_fp8(x)
         dy8, sdy = mod._q_dy.quantize(dy)
@@ -374,7 +403,10 @@ class _ConvSkipFn(torch.autograd.Function):
             if dskip is None:
                 dx = _conv_dgrad(ctx, x, dy)
             else:       # dskip is a gradient buffer this library produced (BN / conv backward): accumulate in place
-                dx = _conv_dgrad(ctx, x, dy, out=_as_grad(dskip, x.dtype), accumulate=True)
+                lazy = _take_lazy(dskip) if (ops.is_nhwc(dskip) and dskip.dtype == x.dtype) else None
+                dx = _conv_dgrad(ctx, x, dy, out=_as_grad(dskip, x.dtype), accumulate=True, acc_mask=lazy)
+        elif dskip is not None:
+            _as_grad(dskip, x.dtype)         # (nobody consumes it: just settle a pending mask entry)
         return dx, None, None
 
 
@@ -437,7 +469,7 @@ class _DeconvFn(torch.autograd.Function):
 
 class _BnFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, gamma, beta, residual, mod, relu, partial=None):
+    def forward(ctx, x, gamma, beta, residual, mod, relu, partial=None, lazy_ok=False):
         # 'fp8' mode: the e4m3 copy of y for the fp8 conv that consumes it is written by the apply pass itself (delayed scale);
         # the very first tensor of the stream is scaled just in time by a stand-alone pass instead
         q8 = None
@@ -456,6 +488,7 @@ class _BnFn(torch.autograd.Function):
         mod._last_q8 = q8 if q8 is not None else ('jit' if emit else None)      # attached to the returned tensor by the module
         ctx.relu = relu
         ctx.mask = mask
+        ctx.lazy_ok = bool(lazy_ok) and _LAZY_RES and mask is not None
         ctx.mod = mod
         ctx.save_for_backward(x, y if keep_y else None, mean, invstd, gamma, beta)
         mod._last_src = (x, bool(keep_y), gamma, beta, mean, invstd, bool(relu))
@@ -464,6 +497,8 @@ class _BnFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         x, y, mean, invstd, gamma, beta = ctx.saved_tensors
+        # dy of a downsample BatchNorm: the unmasked fork gradient of its residual block + the block's ReLU bit mask
+        lazy = _take_lazy(dy) if (not ctx.relu and ctx.mask is None and ops.is_nhwc(dy) and dy.dtype == x.dtype) else None
         dy = _as_grad(dy, x.dtype)
         dg = db = None
         acc = False
@@ -478,13 +513,22 @@ class _BnFn(torch.autograd.Function):
         emit = ctx.emit and _rt.fp8_convs() and ctx.needs_input_grad[0]
         if emit and stream.ready(x.device):
             q8 = (torch.empty_like(x, dtype=torch.uint8), stream.state)
-        dx, dres = ops.bn_bwd(dy, x, y, gamma, mean, invstd, dg, db, acc, ctx.relu, ctx.needs_input_grad[3], beta=beta,
-                              partial=partial, relu_mask=ctx.mask, q8=q8)
+        hand_on = ctx.lazy_ok and ctx.needs_input_grad[3] and lazy is None and partial is None
+        if lazy is not None and partial is None:
+            dx, dres = ops.bn_bwd(dy, x, None, gamma, mean, invstd, dg, db, acc, True, False, beta=beta, relu_mask=lazy, q8=q8)
+        else:
+            if lazy is not None:
+                ops.apply_relu_mask(dy, lazy)
+            dx, dres = ops.bn_bwd(dy, x, y, gamma, mean, invstd, dg, db, acc, ctx.relu, ctx.needs_input_grad[3] and not hand_on,
+                                  beta=beta, partial=partial, relu_mask=ctx.mask, q8=q8)
+        if hand_on:            # the identity branch gets dy itself; its consumer applies the bit mask (see _LAZY_MASK)
+            dres = dy
+            _LAZY_MASK[dy.data_ptr()] = (dy, ctx.mask)
         if emit:       # e5m2 copy of dx for the fp8 input-gradient GEMM of the conv in front (found again by address)
             if q8 is None:
                 q8 = stream.quantize(dx)
             _GRAD_Q8[dx.data_ptr()] = (dx, q8[0], q8[1], ops.E5M2, dx._version)
-        return (dx if ctx.needs_input_grad[0] else None), None, None, dres, None, None, None
+        return (dx if ctx.needs_input_grad[0] else None), None, None, dres, None, None, None, None
 
 
 class _MaxPoolFn(torch.autograd.Function):
@@ -838,7 +882,11 @@ class BatchNorm2d(nn.Module):
                                      'the conv epilogue are stale (use an out-of-place op, or set MI355_BN_STATS_FUSE=0)')
                 if x.shape[1] != self.num_features or not ops.is_nhwc(x):
                     partial = None
-            y = _BnFn.apply(x, self.weight, self.bias, residual, self, bool(relu), partial)
+            # the identity branch's gradient may be handed on unmasked when its producer is one of ours that knows how to apply
+            # the mask: conv1.forward_skip's alias of the block input, or the downsample BatchNorm
+            fn = getattr(residual, 'grad_fn', None) if residual is not None else None
+            lazy_ok = fn is not None and type(fn).__name__ in ('_ConvSkipFnBackward', '_BnFnBackward')
+            y = _BnFn.apply(x, self.weight, self.bias, residual, self, bool(relu), partial, lazy_ok)
             y._mi_bn_src, self._last_src = self._last_src, None     # lets the consumer conv's dgrad reduce dy for this BN
             q8, self._last_q8 = self._last_q8, None
             if q8 == 'jit':

@@ -133,6 +133,21 @@ def conv_dgrad(desc, dy, wT, scale_dev=None, out=None, accumulate=False):
     return dx
 
 
+def conv_dgrad_masked_acc(desc, dy, wT, out, acc_mask, scale_dev=None):
+    """out <- conv_dgrad(dy) + (bit of acc_mask set ? out : 0), in place; returns out."""
+    _chk_dev(dy, wT, out, acc_mask)
+    call('mi355_conv_dgrad_masked_acc', ctypes.byref(desc), ptr(dy), ptr(wT), ptr(scale_dev), ptr(out), ptr(acc_mask), stream_ptr())
+    return out
+
+
+def apply_relu_mask(g, mask):
+    """g <- bit of mask set ? g : 0, in place (g channels_last bf16 / fp32, mask from bn_relu_mask); returns g."""
+    _chk_dev(g, mask)
+    N, C, H, W = g.shape
+    call('mi355_apply_relu_mask', ptr(g), ptr(mask), N * H * W, C, dtype_code(g.dtype), stream_ptr())
+    return g
+
+
 def conv_wgrad(desc, x, dy, dw, accumulate, ws_tag='main'):
     """dw: fp32 buffer in [Co][kh][kw][Ci] memory order (Ci = desc.Ci, i.e. padded for the stem)."""
     _chk_dev(x, dy, dw)

@@ -71,6 +71,12 @@ int mi355_conv_fwd(const mi355_conv_desc* d, const void* x, const void* w, const
                    const void* residual, void* y, void* stream);
 int mi355_conv_dgrad(const mi355_conv_desc* d, const void* dy, const void* wT, const float* bias,
                      const float* scale_dev, int accumulate, void* dx, void* stream);
+/* dx <- result + (bit of acc_mask set ? dx : 0).  acc_mask: the ReLU bit mask of mi355_bn_train_fwd over a tensor shaped like
+ * dx.  The fork of a residual block (torchvision Bottleneck / BasicBlock: out = relu(bn(...) + identity)): dx holds the
+ * gradient of the block's OUTPUT ReLU input, still unmasked, and the conv is the block's first one (same input as the
+ * identity branch); replaces the masked copy mi355_bn_bwd would write as `dresidual` and the add autograd would run. */
+int mi355_conv_dgrad_masked_acc(const mi355_conv_desc* d, const void* dy, const void* wT, const float* scale_dev, void* dx,
+                                const void* acc_mask, void* stream);
 /* Convolution / transposed-convolution forward with the BatchNorm batch statistics of its OUTPUT computed in the
  * epilogue (the nn.BatchNorm2d that follows every conv of resnet.py / pose_resnet2.py:33-41 / regda_7.py:4906-4929 in
  * training mode): partial[slice][Co|Ci][n, mean, M2] per output-row tile, *nslices = slices written (0: this launch
@@ -196,6 +202,10 @@ int mi355_bn_bwd(const void* dy, const void* x, const void* y, const float* gamm
  * launch behind a bounded spin.  MI355_BN_RESIDENT=0 keeps the three-launch form.  *out = spins that gave up since the
  * library was loaded (0 unless a block could not become resident; the results of such a launch are invalid). Synchronises. */
 int mi355_bn_resident_timeouts(unsigned* out);
+/* g <- (bit of relu_mask set) ? g : 0 in place; g [rows][C] bf16 / fp32, relu_mask as above.  The stand-alone form of what
+ * mi355_conv_dgrad_masked_acc and mi355_bn_bwd (relu_mask) do on the fly: a residual block's last BatchNorm hands the
+ * UNMASKED dy on to the other branch (no dresidual write) together with its bit mask (mi355/nn.py _LAZY_MASK). */
+int mi355_apply_relu_mask(void* g, const void* relu_mask, long rows, int C, int dtype, void* stream);
 
 /* ---------------------------------------------------------------- stem max-pool 3x3 s2 p1
  * Replaces nn.MaxPool2d(3,2,1) of the torchvision stem (uda/model/resnet.py:28).  argidx: uint8 window

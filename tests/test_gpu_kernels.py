@@ -122,6 +122,38 @@ def test_conv_residual_epilogue(gpu, dt):
     assert float((_back(y) - ref).abs().max()) <= _tol(dt, ref)
 
 
+@pytest.mark.parametrize('dt', ['f32', 'bf16'])
+@pytest.mark.parametrize('case', [(2, 64, 16, 16, 64, 1, 1, 0), (3, 256, 8, 8, 64, 1, 1, 0), (32, 64, 64, 64, 256, 3, 1, 1), (2, 64, 16, 16, 128, 3, 2, 1)])
+def test_conv_dgrad_accumulates_onto_a_bit_masked_gradient(gpu, dt, case):
+    """dx <- dgrad + (bit ? dx : 0): the fork of a residual block whose identity-branch gradient still lacks the block's
+    ReLU mask (mi355_conv_dgrad_masked_acc), and the stand-alone masking kernel; both against plain tensor arithmetic, and
+    run twice (an earlier build of this epilogue dropped addends now and then -- see the comment in csrc/igemm.hip)."""
+    ops = _ops()
+    N, Ci, H, W, Co, k, s, p = case
+    per = 8 if dt == 'bf16' else 4
+    desc = ops.make_desc(N, H, W, Ci, Co, k, k, s, p, DT[dt])
+    g = torch.Generator(device='cpu').manual_seed(77 + Ci + Co)
+    wm = (torch.randn(Co, k, k, Ci, generator=g) * 0.05).to(gpu)
+    _, wt = ops.pack_weights(wm, Co, k * k, Ci, Ci, DT[dt])
+    dy = ops.nhwc_empty(N, Co, desc.Ho, desc.Wo, DT[dt], gpu).normal_()
+    base = ops.nhwc_empty(N, Ci, H, W, DT[dt], gpu).normal_()
+    mask = torch.randint(0, 256, (N * H * W * Ci // per,), dtype=torch.uint8, device=gpu)
+    bits = ((mask.view(-1, 1) >> torch.arange(per, device=gpu).view(1, per)) & 1).view(N, H, W, Ci).permute(0, 3, 1, 2)
+    dx = ops.conv_dgrad(desc, dy, wt)
+    ref = (base.float() * bits + dx.float())
+    tol = (2e-2 if dt == 'bf16' else 1e-5) * (float(ref.abs().max()) + 1)
+    outs = []
+    for _ in range(2):
+        out = ops.conv_dgrad_masked_acc(desc, dy, wt, base.clone(), mask)
+        assert float((out.float() - ref).abs().max()) <= tol
+        outs.append(out)
+    assert torch.equal(outs[0], outs[1])
+    masked = ops.apply_relu_mask(base.clone(), mask)
+    assert torch.equal(masked.float(), base.float() * bits)
+    with pytest.raises(Exception):
+        ops.conv_dgrad_masked_acc(desc, dy, wt, base.clone(), None)
+
+
 STAT_CASES = [
     # kind, N, Ci, H, W, Co, k, s, p   (kind 'conv': Conv2d; 'deconv': conv-form of ConvTranspose2d(Co -> Ci, 4, 2, 1))
     ('conv', 2, 64, 16, 16, 128, 3, 1, 1),
