@@ -764,9 +764,18 @@ extern "C" int mi355_bn_eval_fwd(const void* x, const void* residual, void* y, c
 
 // ---- resident backward: plan + launch (returns false when the tensor does not fit / the mode is not covered)
 struct BnResPlan { int G, R, rpb, keep; size_t lds; };
+static int g_bn_resident = -1;       // run-time switch (mi355_bn_set_resident); -1: the environment decides
+// The one-launch backward needs every block resident at once.  A caller that runs other kernels BESIDE the backward on the same
+// device (a collective overlapped with it: mi355/da_step.py) switches it off for that stretch: a CU held by the other kernel
+// would keep a block out while the resident ones spin.  Returns the previous setting.
+extern "C" int mi355_bn_set_resident(int on) {
+  const int prev = g_bn_resident;
+  g_bn_resident = on < 0 ? -1 : (on ? 1 : 0);
+  return prev;
+}
 static bool bn_resident_plan(long rows, int C, int CH, BnResPlan* q) {
-  static const bool on = !(getenv("MI355_BN_RESIDENT") && atoi(getenv("MI355_BN_RESIDENT")) == 0);
-  if (!on) return false;
+  static const bool env_on = !(getenv("MI355_BN_RESIDENT") && atoi(getenv("MI355_BN_RESIDENT")) == 0);
+  if (g_bn_resident == 0 || (g_bn_resident < 0 && !env_on)) return false;
   static int ncu = 0; static size_t max_lds = 0;
   if (!ncu) {
     int dev = 0, v = 0;

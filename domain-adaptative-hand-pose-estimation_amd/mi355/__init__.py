@@ -72,6 +72,7 @@ SIGNATURES = {
     'mi355_bn_bwd_partials': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _L, _I, _I, _I, _P, _I, _P, _P, _P, _P, _P]),
     'mi355_bn_bwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _L, _I, _I, _I, _P, _Z, _P, _P, _P, _P]),
     'mi355_bn_resident_timeouts': (_I, [_P]),
+    'mi355_bn_set_resident': (_I, [_I]),
     'mi355_apply_relu_mask': (_I, [_P, _P, _L, _I, _I, _P]),
     'mi355_conv_dgrad_masked_acc': (_I, [_P, _P, _P, _P, _P, _P, _P]),
     'mi355_maxpool_fwd': (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),

@@ -154,11 +154,16 @@ class DAStep:
         """Arm the overlapped reducer for the backward about to run (eager, more than one rank, no side-stream wgrads)."""
         self._reducer = _OverlapReducer(self, keys) if (self.overlap and _distributed() and not _rt.SIDE_WGRAD and
                                                          not torch.cuda.is_current_stream_capturing()) else None
+        if self._reducer is not None:
+            # collectives will run beside this backward: the one-launch BatchNorm backward needs every CU for its resident
+            # blocks (mi355_bn_set_resident), so this pass takes the three-launch form
+            self._bn_resident_prev = _rt.load().mi355_bn_set_resident(0)
 
     def _end_reduce(self, keys):
         r, self._reducer = self._reducer, None
         if r is not None:
             r.finish()
+            _rt.load().mi355_bn_set_resident(self._bn_resident_prev)
         else:
             _allreduce_mean(self._grads(keys))
 

@@ -202,6 +202,10 @@ int mi355_bn_bwd(const void* dy, const void* x, const void* y, const float* gamm
  * launch behind a bounded spin.  MI355_BN_RESIDENT=0 keeps the three-launch form.  *out = spins that gave up since the
  * library was loaded (0 unless a block could not become resident; the results of such a launch are invalid). Synchronises. */
 int mi355_bn_resident_timeouts(unsigned* out);
+/* Run-time switch of the one-launch backward (1 on, 0 off, -1 back to the environment's choice); returns the previous value.
+ * Switch it off while another kernel runs beside the backward on the same device (e.g. a collective overlapped with it): all
+ * blocks of the one-launch form must be resident at once. */
+int mi355_bn_set_resident(int on);
 /* g <- (bit of relu_mask set) ? g : 0 in place; g [rows][C] bf16 / fp32, relu_mask as above.  The stand-alone form of what
  * mi355_conv_dgrad_masked_acc and mi355_bn_bwd (relu_mask) do on the fly: a residual block's last BatchNorm hands the
  * UNMASKED dy on to the other branch (no dresidual write) together with its bit mask (mi355/nn.py _LAZY_MASK). */

@@ -18,7 +18,9 @@ def _free_port():
 def _worker(rank, world, port, overlap, q):
     from conftest import PKG  # noqa: F401  (package source root on sys.path in the spawned process)
     import torch.distributed as dist
-    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), MI355_OVERLAP_ALLREDUCE='1' if overlap else '0')
+    # (same BatchNorm-backward kernels in both runs: the overlapped pass switches the one-launch form off, da_step._begin_reduce)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), MI355_OVERLAP_ALLREDUCE='1' if overlap else '0',
+                      MI355_BN_RESIDENT='0')
     torch.cuda.set_device(0)
     dev = torch.device('cuda', 0)
     dist.init_process_group('gloo', rank=rank, world_size=world)
