@@ -20,7 +20,7 @@ FAMILIES = [            # first match wins
     ('conv_mfma', ('gather_gemm_kernel', 'wgrad_gemm_kernel', 'wgrad_kw_kernel', 'wgrad_kw2_kernel', 'gather_fp8_kernel')),
     ('slab_reduce', ('slab_reduce_kernel',)),
     ('bn_fwd', ('bn_stats_kernel', 'bn_apply_kernel', 'bn_finalize_kernel', 'bn_finalize_wide_kernel')),
-    ('bn_bwd', ('bn_bwd_reduce_kernel', 'bn_bwd_apply_kernel', 'bn_bwd_finalize_kernel')),
+    ('bn_bwd', ('bn_bwd_resident_kernel', 'bn_bwd_reduce_kernel', 'bn_bwd_apply_kernel', 'bn_bwd_finalize_kernel')),
     ('kl_loss', ('kl_heatmap_kernel',)),
     ('argmax', ('argmax2d_kernel',)),
     ('softargmax', ('softargmax_kernel',)),
