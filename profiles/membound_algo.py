@@ -47,9 +47,9 @@ def bn_bwd(dy, x, y, *a, **k):
     return o['bn_bwd'](dy, x, y, *a, **k)
 
 
-def kl(pred, target, weight, eps, want_grad):
+def kl(pred, target, weight, eps, want_grad, *a, **k):
     acc['kl_loss'] += pred.numel() * 4 * (3 if want_grad else 2)
-    return o['kl_heatmap'](pred, target, weight, eps, want_grad)
+    return o['kl_heatmap'](pred, target, weight, eps, want_grad, *a, **k)
 
 
 def am(hm):
