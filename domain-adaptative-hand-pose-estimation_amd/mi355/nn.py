@@ -63,6 +63,7 @@ def _as_feature(x, dtype):
 # fly.  Every other consumer goes through _as_grad, which applies it in place first.  The entry keeps the tensor alive.
 _LAZY_MASK = {}
 _LAZY_RES = _os.environ.get('MI355_BN_LAZY_DRES', '1') == '1'      # A/B switch
+_ZERO_BN_BIAS_GRAD = _os.environ.get('MI355_ZERO_BN_BIAS_GRAD', '1') == '1'      # A/B switch (see _bias_grad)
 
 
 def _take_lazy(g):
@@ -303,10 +304,28 @@ class GradFanIn:
 def _take_partial(mod, y):
     """Move the statistics partials a conv's forward left on its module onto the output tensor (read by BatchNorm2d)."""
     part = mod._last_partial
+    cctx, mod._last_bias_ctx = getattr(mod, '_last_bias_ctx', None), None
     if part is not None:
         mod._last_partial = None
-        y._mi_bn_partial = (part, y._version)      # the version makes an in-place edit of y before the BatchNorm visible
+        # the version makes an in-place edit of y before the BatchNorm visible; cctx: the autograd context of a conv WITH a
+        # bias -- the BatchNorm that takes these partials tells it that its bias gradient is the column sum of a BatchNorm
+        # input gradient, which is zero (see _bias_grad)
+        y._mi_bn_partial = (part, y._version, cctx)
     return y
+
+
+def _bias_grad(ctx, bias, dy):
+    """Bias gradient of a conv = column sum of dy.  When the conv's output went straight into a training-mode BatchNorm (which
+    consumed the statistics fused into this conv's epilogue and said so: ctx.bias_grad_zero), dy is that BatchNorm's input
+    gradient gamma * invstd * (dy_eff - mean(dy_eff) - xhat * mean(dy_eff * xhat)), whose sum over the batch is zero per channel
+    in exact arithmetic (sum xhat = 0): the reference's value there is rounding noise around zero; zero is written instead of
+    running the reduction (19 of the 23 column sums of an iteration)."""
+    g, acc = grad_slot(bias)
+    if getattr(ctx, 'bias_grad_zero', False) and _ZERO_BN_BIAS_GRAD:
+        if not acc:
+            g.zero_()
+        return
+    ops.colsum(dy, g, acc)
 
 
 def _conv_forward(ctx, mod, x, bias, residual, stats_ok=True):
@@ -325,6 +344,7 @@ def _conv_forward(ctx, mod, x, bias, residual, stats_ok=True):
             y, mod._last_partial = ops.conv_fwd_stats(desc, x, wf, bias)
         else:
             y = ops.conv_fwd(desc, x, wf, bias, residual)
+    mod._last_bias_ctx = ctx if (want and bias is not None) else None
     ctx.mod, ctx.desc = mod, desc
     ctx.bn_src = mod._in_bn_src; mod._in_bn_src = None
     return y
@@ -372,8 +392,7 @@ class _ConvFn(torch.autograd.Function):
             elif fan is not None:
                 fan.buf = dx
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            g, acc = grad_slot(bias)
-            ops.colsum(dy, g, acc)
+            _bias_grad(ctx, bias, dy)
         dres = dy if ctx.needs_input_grad[3] else None
         return dx, None, None, dres, None, None, None
 
@@ -633,6 +652,7 @@ class _PwK2CFn(torch.autograd.Function):
         C = weight.shape[0]
         if mod is not None and mod._want_stats():
             out, mod._last_partial = ops.pw_k2c_stats(hm, weight.detach(), bias, C, dtype, residual=residual)
+            mod._last_bias_ctx = ctx if bias is not None else None
         else:
             out = ops.pw_k2c(hm, weight.detach(), bias, C, dtype, residual=residual)
         ctx.has_bias = bias is not None
@@ -659,8 +679,7 @@ class _PwK2CFn(torch.autograd.Function):
             else:
                 ops.pw_wgrad(dout, hm, g, False, acc)
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            g, acc = grad_slot(bias)
-            ops.colsum(dout, g, acc)
+            _bias_grad(ctx, bias, dout)
         dres = dout if ctx.needs_input_grad[3] else None
         return dhm, None, None, dres, None, None
 
@@ -876,12 +895,14 @@ class BatchNorm2d(nn.Module):
             tag = getattr(x, '_mi_bn_partial', None)          # statistics partials from the conv that produced x
             partial = None
             if tag is not None:
-                partial, ver = tag
+                partial, ver, cctx = tag
                 if x._version != ver:
                     raise Mi355Error('the conv output was modified in place before its BatchNorm: the statistics fused into '
                                      'the conv epilogue are stale (use an out-of-place op, or set MI355_BN_STATS_FUSE=0)')
                 if x.shape[1] != self.num_features or not ops.is_nhwc(x):
                     partial = None
+                elif cctx is not None:
+                    cctx.bias_grad_zero = True      # (see _bias_grad)
             # the identity branch's gradient may be handed on unmasked when its producer is one of ours that knows how to apply
             # the mask: conv1.forward_skip's alias of the block input, or the downsample BatchNorm
             fn = getattr(residual, 'grad_fn', None) if residual is not None else None

@@ -287,3 +287,32 @@ def test_gradient_fan_in_is_summed_inside_the_dgrad_epilogues(gpu, dt):
     assert float((g_fan - g_ref).abs().max()) <= (1e-5 if dt == 'f32' else 2e-2) * scale
     for a, b in zip(w_fan, w_ref):
         assert torch.equal(a, b)
+
+
+def test_bias_gradient_of_a_conv_in_front_of_a_training_mode_batchnorm(gpu):
+    """conv(+bias) -> BatchNorm2d (training) -> ReLU: the bias gradient is the column sum of the BatchNorm's input gradient,
+    which is zero per channel up to rounding; the library writes exact zeros instead of reducing (mi355/nn.py _bias_grad).
+    The torch reference shows the size of what is dropped; a conv whose output does NOT go into a BatchNorm keeps its real
+    bias gradient; the other gradients are unaffected."""
+    import torch.nn as tnn
+    import mi355
+    from mi355.nn import Conv2d, BatchNorm2d, FusedSequential, ReLU
+    mi355.set_compute_dtype('f32')
+    seq = FusedSequential(Conv2d(16, 32, 3, 1, 1, bias=True), BatchNorm2d(32), ReLU(), Conv2d(32, 16, 1, 1, 0, bias=True)).to(gpu)
+    ref = tnn.Sequential(tnn.Conv2d(16, 32, 3, 1, 1, bias=True), tnn.BatchNorm2d(32), tnn.ReLU(), tnn.Conv2d(32, 16, 1, 1, 0, bias=True)).to(gpu)
+    fill_module_(seq, 300)
+    with torch.no_grad():
+        ref[0].weight.copy_(seq[0].weight); ref[0].bias.copy_(seq[0].bias)
+        ref[1].weight.copy_(seq[1].weight); ref[1].bias.copy_(seq[1].bias)
+        ref[3].weight.copy_(seq[3].weight); ref[3].bias.copy_(seq[3].bias)
+    x = randn(301, 4, 16, 10, 10).to(gpu)
+    t = randn(302, 4, 16, 10, 10).to(gpu)
+    seq.train(); ref.train()
+    (seq(x.contiguous(memory_format=torch.channels_last)).float() * t).sum().backward()
+    (ref(x) * t).sum().backward()
+    assert float(seq[0].bias.grad.abs().max()) == 0.0
+    assert float(ref[0].bias.grad.abs().max()) <= 1e-4 * float(ref[3].bias.grad.abs().max())       # rounding noise in the reference
+    close = lambda a, b: float((a - b).abs().max()) <= 1e-3 * (float(b.abs().max()) + 1e-6)
+    assert close(seq[3].bias.grad, ref[3].bias.grad)
+    assert close(seq[0].weight.grad, ref[0].weight.grad) and close(seq[3].weight.grad, ref[3].weight.grad)
+    assert close(seq[1].weight.grad, ref[1].weight.grad) and close(seq[1].bias.grad, ref[1].bias.grad)

@@ -518,7 +518,10 @@ def test_full_size_bf16_iteration_properties(gpu, arch, last_bn):
                 assert torch.equal(p, before[k]), k
             else:
                 assert torch.isfinite(p).all(), k
-                assert not torch.equal(p, before[k]), 'parameter %s was not updated' % k
+                # a conv bias in front of a training-mode BatchNorm starts at 0 and its gradient is exactly 0 (the column sum
+                # of a BatchNorm input gradient; the reference moves it by rounding noise): it may stay where it was
+                inert = k.endswith('.bias') and p.grad is not None and float(p.grad.abs().max()) == 0.0 and float(before[k].abs().max()) == 0.0
+                assert inert or not torch.equal(p, before[k]), 'parameter %s was not updated' % k
         out2 = step.run(batch)
         torch.cuda.synchronize()
         assert all(np.isfinite(float(out2[k])) for k in ('loss_s', 'loss_gf', 'loss_gt'))
