@@ -126,6 +126,8 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X: the HIP path has no CPU fallback')
     dev_index = local_rank if args.backend == 'nccl' else 0
+    if world > 1 and args.backend != 'nccl':
+        os.environ['MI355_BN_RESIDENT'] = '0'      # ranks share one GPU: no kernel may claim every CU for resident blocks
     torch.cuda.set_device(dev_index)
     dev = torch.device('cuda', dev_index)
     if world > 1:

@@ -66,6 +66,10 @@ def init_distributed():
             raise SystemExit('this training path needs an MI355X (HIP kernels only, no CPU fallback)')
         torch.cuda.set_device(local % ndev)
         device = torch.device('cuda', local % ndev)
+        if WORLD > ndev:
+            # several ranks share a GPU (rehearsal): the one-launch BatchNorm backward wants the whole chip for its resident
+            # blocks -- two processes launching it at once would starve each other (include/mi355pose.h, mi355_bn_set_resident)
+            os.environ['MI355_BN_RESIDENT'] = '0'
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         dist.init_process_group(os.environ.get('MI355_DIST_BACKEND', 'nccl'), rank=RANK, world_size=WORLD)
     return RANK, WORLD

@@ -204,7 +204,9 @@ int mi355_bn_bwd(const void* dy, const void* x, const void* y, const float* gamm
 int mi355_bn_resident_timeouts(unsigned* out);
 /* Run-time switch of the one-launch backward (1 on, 0 off, -1 back to the environment's choice); returns the previous value.
  * Switch it off while another kernel runs beside the backward on the same device (e.g. a collective overlapped with it): all
- * blocks of the one-launch form must be resident at once. */
+ * blocks of the one-launch form must be resident at once.  For the same reason two PROCESSES that share a GPU must not both use it
+ * (train1.py / bench.py set MI355_BN_RESIDENT=0 when ranks share a device); a launch whose blocks could not all become resident
+ * gives up after about 0.3 s and is counted by mi355_bn_resident_timeouts. */
 int mi355_bn_set_resident(int on);
 /* g <- (bit of relu_mask set) ? g : 0 in place; g [rows][C] bf16 / fp32, relu_mask as above.  The stand-alone form of what
  * mi355_conv_dgrad_masked_acc and mi355_bn_bwd (relu_mask) do on the fly: a residual block's last BatchNorm hands the
