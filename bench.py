@@ -215,14 +215,16 @@ def main():
     if not args.no_eval:
         model.eval()
         from utils.keypoint_detection import get_max_preds_device
+        from mi355.infer import GraphedForward
+        forward = GraphedForward(model)                     # what validate() of train1.py / test.py runs
         with torch.no_grad():
-            for _ in range(3):
-                get_max_preds_device(model(batch['x_t']))
+            for _ in range(4):
+                get_max_preds_device(forward(batch['x_t']))
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            n_eval = 10
+            n_eval = 20
             for _ in range(n_eval):
-                get_max_preds_device(model(batch['x_t']))
+                get_max_preds_device(forward(batch['x_t']))
             torch.cuda.synchronize()
             eval_ms = (time.perf_counter() - t0) / n_eval * 1e3
         model.train()
@@ -297,6 +299,7 @@ def main():
             'model_passes_per_s': round(3 * B * world / (ms_per_step * 1e-3), 2),
             'eval_images_per_s_per_gpu': round(B / (eval_ms * 1e-3), 1) if eval_ms else None,
             'losses_last_step': losses,
+            'bn_resident_timeouts': ops.bn_resident_timeouts(),      # 0 = every one-launch BatchNorm backward had all its blocks resident
         }
         if F is not None:
             tf = 9 * B * F * 1e9 / (ms_per_step * 1e-3) / 1e12

@@ -410,6 +410,9 @@ __global__ __launch_bounds__(64 * WGM * WGN, (KW3 && BM == 256) ? 2 : 1) void ga
         float w[CH]; Chunk<T>::unpack(q, w);
 #pragma unroll
         for (int e = 0; e < CH; ++e) v[e] += w[e]; }
+      if (p.relu) {
+#pragma unroll
+        for (int e = 0; e < CH; ++e) v[e] = v[e] < 0.f ? 0.f : v[e]; }      // (keeps NaN, like ATen relu)
       Chunk<T>::store(D + g, v);
     }
   } else {
@@ -1260,10 +1263,12 @@ static int check_bnb(const mi355_bn_bwd_src* bn, const float* partial, const int
 struct Fp8Extra { const float* descale_a; const float* descale_b; int a_fmt; };
 static int conv_fwd_impl(const mi355_conv_desc* d, const void* x, const void* w, const float* bias, const void* residual, void* y,
                          float* partial, size_t partial_bytes, int* nslices, void* stream, const mi355_bn_bwd_src* bn = nullptr,
-                         const Fp8Extra* f8 = nullptr) {
+                         const Fp8Extra* f8 = nullptr, int relu = 0) {
   if (int e = check_desc(d)) return e;
   if ((d->dtype == MI355_FP8) != (f8 != nullptr)) MI_FAIL(MI355_EINVAL, "fp8 descriptors go through the *_fp8 entry points (and only they)");
+  if (relu && (bn || f8 || partial)) MI_FAIL(MI355_EINVAL, "conv_fwd: the fused ReLU is an inference epilogue (no statistics / BatchNorm-backward / fp8 variant)");
   GatherArgs a; memset(&a, 0, sizeof(a));
+  a.relu = relu ? 1 : 0;
   a.A = x; a.B = w; a.D = y; a.bias = bias; a.residual = residual; a.scale = nullptr;
   a.Hi = d->Hi; a.Wi = d->Wi; a.Ci = d->Ci; a.in_sy = a.in_sx = d->stride;
   a.Ho = d->Ho; a.Wo = d->Wo; a.out_sy = a.out_sx = 1;
@@ -1290,6 +1295,11 @@ extern "C" int mi355_conv_fwd_fp8(const mi355_conv_desc* d, const void* x8, int 
 extern "C" int mi355_conv_fwd(const mi355_conv_desc* d, const void* x, const void* w, const float* bias,
                               const void* residual, void* y, void* stream) {
   return conv_fwd_impl(d, x, w, bias, residual, y, nullptr, 0, nullptr, stream);
+}
+// inference: y = act(conv(x) + bias + residual) -- with the BatchNorm that follows folded into w / bias by the caller
+extern "C" int mi355_conv_fwd_act(const mi355_conv_desc* d, const void* x, const void* w, const float* bias, const void* residual,
+                                  int relu, void* y, void* stream) {
+  return conv_fwd_impl(d, x, w, bias, residual, y, nullptr, 0, nullptr, stream, nullptr, nullptr, relu);
 }
 extern "C" int mi355_conv_fwd_stats(const mi355_conv_desc* d, const void* x, const void* w, const float* bias, void* y,
                                     float* partial, size_t partial_bytes, int* nslices, void* stream) {
@@ -1338,7 +1348,8 @@ extern "C" int mi355_conv1x1_heatmap(const void* x, const void* w, const float* 
 // decomposed into stride^2 phases (iy%s, ix%s), each a unit-stride gather over its own tap subset.
 static int conv_dgrad_impl(const mi355_conv_desc* d, const void* dy, const void* wT, const float* bias, const float* scale_dev,
                            int accumulate, void* dx, float* partial, size_t partial_bytes, int* nslices, void* stream,
-                           const mi355_bn_bwd_src* bn = nullptr, const Fp8Extra* f8 = nullptr, const void* acc_mask = nullptr);
+                           const mi355_bn_bwd_src* bn = nullptr, const Fp8Extra* f8 = nullptr, const void* acc_mask = nullptr,
+                           int relu = 0);
 extern "C" int mi355_conv_dgrad_fp8(const mi355_conv_desc* d, const void* dy8, int dy_fmt, const void* wT8, const float* descale_dy,
                                     const float* descale_w, const float* scale_dev, int accumulate, void* dx, float* partial,
                                     size_t partial_bytes, int* nslices, void* stream) {
@@ -1364,6 +1375,11 @@ extern "C" int mi355_conv_dgrad_masked_acc(const mi355_conv_desc* d, const void*
   if (!acc_mask) MI_FAIL(MI355_EINVAL, "conv_dgrad_masked_acc: acc_mask is null");
   return conv_dgrad_impl(d, dy, wT, nullptr, scale_dev, 1, dx, nullptr, 0, nullptr, stream, nullptr, nullptr, acc_mask);
 }
+// inference ConvTranspose2d forward: dx = act(dgrad(dy) + bias) with the following BatchNorm folded into wT / bias
+extern "C" int mi355_conv_dgrad_act(const mi355_conv_desc* d, const void* dy, const void* wT, const float* bias, int relu, void* dx,
+                                    void* stream) {
+  return conv_dgrad_impl(d, dy, wT, bias, nullptr, 0, dx, nullptr, 0, nullptr, stream, nullptr, nullptr, nullptr, relu);
+}
 // ConvTranspose2d forward (= conv-form dgrad) with the BatchNorm statistics of its output fused into the epilogue
 extern "C" int mi355_conv_dgrad_stats(const mi355_conv_desc* d, const void* dy, const void* wT, void* dx, float* partial,
                                       size_t partial_bytes, int* nslices, void* stream) {
@@ -1372,8 +1388,9 @@ extern "C" int mi355_conv_dgrad_stats(const mi355_conv_desc* d, const void* dy, 
 }
 static int conv_dgrad_impl(const mi355_conv_desc* d, const void* dy, const void* wT, const float* bias, const float* scale_dev,
                            int accumulate, void* dx, float* partial, size_t partial_bytes, int* nslices, void* stream,
-                           const mi355_bn_bwd_src* bn, const Fp8Extra* f8, const void* acc_mask) {
+                           const mi355_bn_bwd_src* bn, const Fp8Extra* f8, const void* acc_mask, int relu) {
   if (nslices) *nslices = 0;
+  if (relu && (bn || f8 || partial || accumulate)) MI_FAIL(MI355_EINVAL, "conv_dgrad: the fused ReLU is an inference epilogue of the transposed conv");
   if (acc_mask && (!accumulate || bn || f8)) MI_FAIL(MI355_EINVAL, "conv_dgrad: acc_mask goes with accumulate = 1 on the plain bf16 / fp32 path only");
   if (int e = check_desc(d)) return e;
   if ((d->dtype == MI355_FP8) != (f8 != nullptr)) MI_FAIL(MI355_EINVAL, "fp8 descriptors go through the *_fp8 entry points (and only they)");
@@ -1403,6 +1420,7 @@ static int conv_dgrad_impl(const mi355_conv_desc* d, const void* dy, const void*
   a.Nout = d->Ci; a.ldd = d->Ci; a.ldb = d->kh * d->kw * d->Co;
   a.accumulate = accumulate ? 1 : 0;
   a.acc_mask = reinterpret_cast<const unsigned char*>(acc_mask);
+  a.relu = relu ? 1 : 0;
   int nt = 0;
   for (int py = 0; py < s; ++py)
     for (int px = 0; px < s; ++px) {

@@ -41,6 +41,7 @@ struct GatherArgs {
   // accumulate = 1 only: the value already in D is kept where its bit is set ([rows][ldd / chunk] bytes, bit e = channel
   // chunk * chunk_size + e: the ReLU bit mask of BatchNorm's forward) -- D + this launch's result = masked fork gradient
   const unsigned char* acc_mask;
+  int relu;                    // max(0, .) on the finished value (inference: conv + folded BatchNorm + ReLU in one launch)
 };
 
 // 16-byte chunk with the elements whose mask bit is clear set to zero (bit e = element e; bf16: two elements per word)

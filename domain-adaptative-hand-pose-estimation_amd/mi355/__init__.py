@@ -75,6 +75,8 @@ SIGNATURES = {
     'mi355_bn_set_resident': (_I, [_I]),
     'mi355_apply_relu_mask': (_I, [_P, _P, _L, _I, _I, _P]),
     'mi355_conv_dgrad_masked_acc': (_I, [_P, _P, _P, _P, _P, _P, _P]),
+    'mi355_conv_fwd_act': (_I, [_P, _P, _P, _P, _P, _I, _P, _P]),
+    'mi355_conv_dgrad_act': (_I, [_P, _P, _P, _P, _I, _P, _P]),
     'mi355_maxpool_fwd': (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
     'mi355_maxpool_bwd': (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
     'mi355_nchw_to_nhwc': (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),

@@ -46,8 +46,63 @@ def _param_version(p):
     return (p._version, getattr(p, '_mi_epoch', 0), p.data_ptr())
 
 
+# ---- inference: conv -> eval-mode BatchNorm (-> + identity) -> ReLU as ONE launch (test.py's forward-only path)
+# A conv / deconv that is followed by a BatchNorm (link_conv_bn) does not run in eval mode under no_grad: it returns a
+# _LazyConv; the BatchNorm2d that receives it folds its running statistics into the conv's weights and bias (cached until a
+# parameter or a running statistic changes) and launches conv + bias + residual + ReLU (mi355_conv_fwd_act /
+# mi355_conv_dgrad_act).  Any other mi355 layer that receives a _LazyConv runs the plain conv first (_as_feature).
+_EVAL_FOLD = _os.environ.get('MI355_EVAL_FOLD_BN', '1') == '1'
+_BN_GEN = [0]        # bumped by every training-mode BatchNorm forward: its kernels update running statistics in place
+
+
+class _LazyConv:
+    __slots__ = ('conv', 'x')
+
+    def __init__(self, conv, x):
+        self.conv, self.x = conv, x
+
+    def materialize(self):
+        return self.conv(self.x, _lazy=False)
+
+
+class _FoldedBn:
+    """Weights and bias of one conv with the eval-mode BatchNorm behind it folded in."""
+
+    def __init__(self):
+        self.key, self.w, self.bias = None, None, None
+
+    def get(self, conv, bn, dtype, deconv):
+        ver = lambda t: None if t is None else _param_version(t)
+        key = (ver(conv.weight), ver(conv.bias), ver(bn.weight), ver(bn.bias), bn.running_mean._version, bn.running_var._version,
+               _BN_GEN[0], dtype, id(bn), float(bn.eps))
+        if key != self.key:
+            with torch.no_grad():
+                scale = bn.weight.detach().float() / torch.sqrt(bn.running_var.float() + bn.eps)
+                shift = bn.bias.detach().float() - bn.running_mean.float() * scale
+                if conv.bias is not None:
+                    shift = shift + conv.bias.detach().float() * scale
+                wm = conv.weight.detach().permute(0, 2, 3, 1)            # memory order [O][kh][kw][I], contiguous view
+                k2 = conv.kernel_size[0] * conv.kernel_size[1]
+                if deconv:       # conv-form (O = in_channels, I = out_channels): the deconv's OUTPUT channels are I
+                    wm = (wm * scale.view(1, 1, 1, -1)).contiguous()
+                    _, self.w = ops.pack_weights(wm, conv.in_channels, k2, conv.out_channels, conv.out_channels, dtype, want_f=False, want_t=True)
+                else:
+                    wm = (wm * scale.view(-1, 1, 1, 1)).contiguous()
+                    self.w, _ = ops.pack_weights(wm, conv.out_channels, k2, conv.in_channels, conv._cin_pad(dtype), dtype, want_f=True, want_t=False)
+                self.bias = shift.contiguous()
+            self.key = key
+        return self.w, self.bias
+
+
+def _lazy_ok(mod, residual=None):
+    return (_EVAL_FOLD and mod.bn_follows and not mod.training and not torch.is_grad_enabled() and residual is None and
+            getattr(mod, 'mode', 'mfma') == 'mfma' and not _rt.fp8_convs())
+
+
 def _as_feature(x, dtype):
     """Accept anything NCHW-shaped; hand the kernels a channels_last tensor of the compute dtype."""
+    if isinstance(x, _LazyConv):
+        x = x.materialize()
     if ops.is_nhwc(x) and x.dtype == dtype:
         return x
     if not x.is_cuda:
@@ -501,6 +556,7 @@ class _BnFn(torch.autograd.Function):
         keep_y = relu and (_MASK_FROM_Y or (residual is not None and (_FUSE_BNBWD or not _RELU_BITMASK)))
         mask = ops.bn_relu_mask(x) if (relu and residual is not None and not keep_y and
                                        (x.requires_grad or gamma.requires_grad)) else None
+        _BN_GEN[0] += 1
         y, mean, invstd = ops.bn_train_fwd(x, residual, gamma, beta, mod.running_mean, mod.running_var,
                                            mod.num_batches_tracked, mod.eps, mod.momentum, relu, _rt.bn_stat_updates,
                                            partial=partial, relu_mask=mask, q8=q8)
@@ -701,6 +757,7 @@ class Conv2d(nn.Module):
         self._packed8, self._q_in, self._q_dy = _PackedFp8(), _Fp8Stream(ops.E4M3), _Fp8Stream(ops.E5M2)
         self._cast = _CastCopy()
         self._cast_t = _CastCopy(transposed=True)
+        self._folded = _FoldedBn()
         self._stem_tmp = None
         self._last_partial = None
         self._in_bn_src = None
@@ -784,7 +841,9 @@ class Conv2d(nn.Module):
             dst = g.permute(0, 2, 3, 1)
             dst.add_(src) if acc else dst.copy_(src)
 
-    def forward(self, x, residual=None):
+    def forward(self, x, residual=None, _lazy=True):
+        if _lazy and _lazy_ok(self, residual) and not isinstance(x, _LazyConv):
+            return _LazyConv(self, x)
         dtype = compute_dtype()
         mode = self.mode
         scale = None
@@ -808,8 +867,27 @@ class Conv2d(nn.Module):
         fan = getattr(x, '_mi_fan', None) if torch.is_grad_enabled() and x.requires_grad else None
         return _take_partial(self, _ConvFn.apply(x, self.weight, self.bias, residual, self, scale, fan))
 
+    def _input_feature(self, x, dtype):
+        if x.shape[1] == self.in_channels and self.in_channels != self._cin_pad(dtype):
+            return ops.to_nhwc(x if (x.dtype == torch.float32 and x.is_contiguous()) else x.float().contiguous(), dtype, self._cin_pad(dtype))
+        return _as_feature(x, dtype)
+
+    def forward_folded(self, x, bn, residual, relu):
+        """act(conv(x) * scale + shift + residual) with bn's running statistics folded into the operands (inference)."""
+        dtype = compute_dtype()
+        x = self._input_feature(x, dtype)
+        N, C, H, W = x.shape
+        k = self.kernel_size[0]
+        desc = ops.make_desc(N, H, W, C, self.out_channels, k, k, self.stride[0], self.padding[0], x.dtype)
+        wf, bias = self._folded.get(self, bn, dtype, False)
+        if residual is not None:
+            residual = _as_feature(residual, dtype)
+        return ops.conv_fwd(desc, x, wf, bias, residual, relu=bool(relu))
+
     def forward_skip(self, x):
         """(conv(x), alias of x): for residual blocks, see _ConvSkipFn.  Bias-free MFMA convs only."""
+        if _lazy_ok(self):
+            return self.forward(x), x
         if not _SKIP_FUSE or self.mode != 'mfma' or self.bias is not None or getattr(x, '_mi_gl', None) is not None or \
                 self.in_channels != self._cin_pad(compute_dtype()):
             return self.forward(x), x
@@ -835,6 +913,7 @@ class ConvTranspose2d(nn.Module):
         self.weight = _convform_param(in_channels, out_channels, kernel_size, kernel_size)
         self.bias = None
         self._packed = _PackedWeights()
+        self._folded = _FoldedBn()
         self._packed8, self._q_in, self._q_dy = _PackedFp8(), _Fp8Stream(ops.E4M3), _Fp8Stream(ops.E5M2)
         self._last_partial = None
         self._in_bn_src = None
@@ -865,10 +944,21 @@ class ConvTranspose2d(nn.Module):
         wf, wt = self._packed.get(self.weight, self.in_channels, k * k, self.out_channels, self.out_channels, x.dtype)
         return desc, wf, wt
 
-    def forward(self, x):
+    def forward(self, x, _lazy=True):
+        if _lazy and _lazy_ok(self) and not isinstance(x, _LazyConv):
+            return _LazyConv(self, x)
         x = _as_feature(x, compute_dtype())
         self._in_bn_src = _bn_src_of(x)
         return _take_partial(self, _DeconvFn.apply(x, self.weight, self))
+
+    def forward_folded(self, x, bn, residual, relu):
+        dtype = compute_dtype()
+        x = _as_feature(x, dtype)
+        if residual is not None:            # (not a shape of the model: plain deconv, then the BatchNorm's own kernel)
+            return ops.bn_eval_fwd(self(x, _lazy=False), _as_feature(residual, dtype), bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, relu)
+        desc, _, _ = self._plan(x)
+        wt, bias = self._folded.get(self, bn, dtype, True)
+        return ops.deconv_fwd_act(desc, x, wt, bias, relu=bool(relu))
 
     def _want_stats(self):
         return _FUSE_STATS and self.training and self.bn_follows
@@ -890,6 +980,10 @@ class BatchNorm2d(nn.Module):
         return '{num_features}, eps={eps}, momentum={momentum}'.format(num_features=self.num_features, eps=self.eps, momentum=self.momentum)
 
     def forward(self, x, residual=None, relu=False):
+        if isinstance(x, _LazyConv):
+            if not self.training and not torch.is_grad_enabled() and x.conv.weight.shape[0 if isinstance(x.conv, Conv2d) else 1] == self.num_features:
+                return x.conv.forward_folded(x.x, self, residual, relu)       # conv + this BatchNorm (+ residual, ReLU): one launch
+            x = x.materialize()
         x = _as_feature(x, compute_dtype())
         if self.training:
             tag = getattr(x, '_mi_bn_partial', None)          # statistics partials from the conv that produced x

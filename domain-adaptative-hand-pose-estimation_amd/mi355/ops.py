@@ -60,10 +60,21 @@ def make_desc(N, Hi, Wi, Ci, Co, kh, kw, stride, pad, dtype):
 
 
 # ---------------------------------------------------------------- convolution family
-def conv_fwd(desc, x, w, bias=None, residual=None):
+def conv_fwd(desc, x, w, bias=None, residual=None, relu=False):
     _chk_dev(x, w)
     y = nhwc_empty(desc.N, desc.Co, desc.Ho, desc.Wo, x.dtype, x.device)
-    call('mi355_conv_fwd', ctypes.byref(desc), ptr(x), ptr(w), ptr(bias), ptr(residual), ptr(y), stream_ptr())
+    if relu:
+        call('mi355_conv_fwd_act', ctypes.byref(desc), ptr(x), ptr(w), ptr(bias), ptr(residual), 1, ptr(y), stream_ptr())
+    else:
+        call('mi355_conv_fwd', ctypes.byref(desc), ptr(x), ptr(w), ptr(bias), ptr(residual), ptr(y), stream_ptr())
+    return y
+
+
+def deconv_fwd_act(desc, x, wT, bias=None, relu=False):
+    """Inference ConvTranspose2d forward (conv-form dgrad) + bias + ReLU in one launch."""
+    _chk_dev(x, wT)
+    y = nhwc_empty(desc.N, desc.Ci, desc.Hi, desc.Wi, x.dtype, x.device)
+    call('mi355_conv_dgrad_act', ctypes.byref(desc), ptr(x), ptr(wT), ptr(bias), int(bool(relu)), ptr(y), stream_ptr())
     return y
 
 

@@ -322,11 +322,13 @@ def validate(val_loader, model, criterion, args):
     acc = AverageMeterDict(val_loader.dataset.keypoints_group.keys(), ":3.2f")
     progress = ProgressMeter(len(val_loader), [batch_time, losses, acc['all']], prefix='Test: ')
     model.eval()
+    from mi355.infer import GraphedForward
+    forward = GraphedForward(model)          # full batches replay one HIP graph; the ragged last batch runs eagerly
     with torch.no_grad():
         end = time.time()
         for i, (x, label, weight, meta) in enumerate(val_loader):
             x, label, weight = x.to(device), label.to(device), weight.to(device)
-            y = model(x)
+            y = forward(x)
             loss = criterion(y, label, weight)
             losses.update(loss.item(), x.size(0))
             acc_per_points, avg_acc, cnt, pred = accuracy(y, label)

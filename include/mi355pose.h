@@ -71,6 +71,14 @@ int mi355_conv_fwd(const mi355_conv_desc* d, const void* x, const void* w, const
                    const void* residual, void* y, void* stream);
 int mi355_conv_dgrad(const mi355_conv_desc* d, const void* dy, const void* wT, const float* bias,
                      const float* scale_dev, int accumulate, void* dx, void* stream);
+/* Inference forms: y = act(conv(x) + bias + residual), dx = act(dgrad(dy) + bias) (the ConvTranspose2d forward), act = ReLU when
+ * relu != 0.  The caller folds an eval-mode BatchNorm that follows into the operands (w * gamma / sqrt(var + eps) per output
+ * channel, bias = beta - mean * that scale): conv -> BN -> (+identity) -> ReLU of resnet.py / pose_resnet2.py:33-41 /
+ * regda_7.py:4906-4929 becomes one launch in test.py's forward-only path. */
+int mi355_conv_fwd_act(const mi355_conv_desc* d, const void* x, const void* w, const float* bias, const void* residual, int relu,
+                       void* y, void* stream);
+int mi355_conv_dgrad_act(const mi355_conv_desc* d, const void* dy, const void* wT, const float* bias, int relu, void* dx,
+                         void* stream);
 /* dx <- result + (bit of acc_mask set ? dx : 0).  acc_mask: the ReLU bit mask of mi355_bn_train_fwd over a tensor shaped like
  * dx.  The fork of a residual block (torchvision Bottleneck / BasicBlock: out = relu(bn(...) + identity)): dx holds the
  * gradient of the block's OUTPUT ReLU input, still unmasked, and the conv is the block's first one (same input as the

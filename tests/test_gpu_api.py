@@ -316,3 +316,49 @@ def test_bias_gradient_of_a_conv_in_front_of_a_training_mode_batchnorm(gpu):
     assert close(seq[3].bias.grad, ref[3].bias.grad)
     assert close(seq[0].weight.grad, ref[0].weight.grad) and close(seq[3].weight.grad, ref[3].weight.grad)
     assert close(seq[1].weight.grad, ref[1].weight.grad) and close(seq[1].bias.grad, ref[1].bias.grad)
+
+
+@pytest.mark.parametrize('dt', ['f32', 'bf16'])
+def test_eval_forward_folds_batchnorm_and_replays_from_a_graph(gpu, dt):
+    """test.py's forward-only path: (1) in eval mode under no_grad every conv -> BatchNorm (-> + identity) -> ReLU runs as one
+    launch with the running statistics folded into the conv's operands -- same heat-maps as the unfolded kernels within
+    rounding; (2) GraphedForward replays that forward from a HIP graph, follows parameter / statistic changes (a training
+    iteration in between) and leaves other shapes to the eager path."""
+    import mi355
+    import mi355.nn as mnn
+    from mi355.infer import GraphedForward
+    import uda.model as models
+    from uda.model.pose_resnet2 import Upsampling, PoseResNet
+    mi355.set_compute_dtype(dt)
+    try:
+        torch.manual_seed(3)
+        bb = models.resnet50(pretrained=False)
+        model = PoseResNet(bb, Upsampling(bb.out_features), 256, 21, finetune=True).to(gpu)
+        x = randn(400, 4, 3, 64, 64).to(gpu)
+        model.train()
+        for _ in range(2):                                   # running statistics away from their initial values
+            model(x)
+        model.eval()
+        tol = 3e-2 if dt == 'bf16' else 1e-4
+        with torch.no_grad():
+            y_fold = model(x)
+            mnn._EVAL_FOLD = False
+            try:
+                y_plain = model(x)
+            finally:
+                mnn._EVAL_FOLD = True
+            scale = float(y_plain.abs().max())
+            assert float((y_fold - y_plain).abs().max()) <= tol * scale
+            fwd = GraphedForward(model, warmup=1)
+            outs = [fwd(x) for _ in range(4)]                # eager, capture + replay, replay, replay
+            for o in outs:
+                assert torch.equal(o, y_fold)
+            assert len(fwd._graphs) == 1
+            y_small = fwd(x[:2])                             # another shape: eager until seen often enough
+            assert float((y_small - model(x[:2])).abs().max()) == 0.0
+        model.train(); model(x); model.eval()                # statistics moved: the graphs must go
+        with torch.no_grad():
+            y_new = model(x)
+            assert torch.equal(fwd(x), y_new) and not torch.equal(y_new, y_fold)
+    finally:
+        mi355.set_compute_dtype('f32')
