@@ -24,16 +24,34 @@ from . import ops
 from .nn import mark_grads_fresh
 
 
+# MI355_GRAD_BUCKET_BF16=1 (opt-in): the fp32 gradient ranges travel as bf16 copies -- half the bytes on every xGMI link, one
+# cast each way (read 4 + write 2 bytes per element) -- and are averaged in bf16.  Default: fp32, as the reference would.
+BF16_BUCKETS = os.environ.get('MI355_GRAD_BUCKET_BF16', '0') == '1'
+
+
+def _reduce_mean_(t, async_op=False):
+    """In-place mean of tensor t over the ranks; returns (work or None, finish) -- finish() after the wait completes the job."""
+    avg = dist.get_backend() == 'nccl'
+    ws = dist.get_world_size()
+    if BF16_BUCKETS and t.dtype == torch.float32:
+        low = t.to(torch.bfloat16)
+        w = dist.all_reduce(low, op=dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM, async_op=async_op)
+
+        def finish():
+            t.copy_(low)
+            if not avg:
+                t.div_(ws)
+        return w, finish
+    w = dist.all_reduce(t, op=dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM, async_op=async_op)
+    return w, ((lambda: None) if avg else (lambda: t.div_(ws)))
+
+
 def _allreduce_mean(bufs):
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return
-    ws = dist.get_world_size()
     for b in bufs:
-        if dist.get_backend() == 'nccl':
-            dist.all_reduce(b, op=dist.ReduceOp.AVG)
-        else:
-            dist.all_reduce(b, op=dist.ReduceOp.SUM)
-            b.div_(ws)
+        _, finish = _reduce_mean_(b)
+        finish()
 
 
 def _distributed():
@@ -56,8 +74,8 @@ class _OverlapReducer:
 
     def _launch(self, G, lo, hi):
         t = G[lo:hi]
-        w = dist.all_reduce(t, op=dist.ReduceOp.AVG if self.avg else dist.ReduceOp.SUM, async_op=True)
-        self.works.append((w, t))
+        w, finish = _reduce_mean_(t, async_op=True)
+        self.works.append((w, finish))
         self.covered.setdefault(G.data_ptr(), []).append((lo, hi))
 
     def stage_done(self, stage):
@@ -78,11 +96,9 @@ class _OverlapReducer:
                 if lo > pos:
                     self._launch(G, pos, lo)
                 pos = max(pos, hi)
-        ws = dist.get_world_size()
-        for w, t in self.works:
+        for w, done in self.works:
             w.wait()
-            if not self.avg:
-                t.div_(ws)
+            done()
         self.works = []
 
 

@@ -162,3 +162,40 @@ def test_every_stepped_parameter_is_reduced_exactly_once():
             assert early >= 5 and total > early, (rank, name, early, total)      # pieces launched from the hooks + the tail
         assert rep['B'] is True
         assert rep['slots'] == (True, True), rep['slots']
+
+
+def _worker_bf16(rank, world, port, q):
+    from conftest import PKG  # noqa: F401
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), MI355_GRAD_BUCKET_BF16='1')
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    import mi355.da_step as ds
+    assert ds.BF16_BUCKETS
+    g = torch.Generator().manual_seed(7 + rank)
+    buf = torch.randn(1000, generator=g)
+    mine = buf.clone()
+    ds._allreduce_mean([buf])
+    w, finish = ds._reduce_mean_(mine, async_op=True)      # the overlapped reducer's form
+    w.wait(); finish()
+    q.put((rank, buf.numpy().copy(), mine.numpy().copy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bf16_gradient_buckets_average_within_bf16_rounding():
+    """MI355_GRAD_BUCKET_BF16=1: the fp32 gradient ranges are exchanged as bf16 copies; every rank ends with the same values,
+    the mean of the bf16-rounded inputs up to one more bf16 rounding."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_bf16, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=120) for _ in range(world)), key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    inputs = [torch.randn(1000, generator=torch.Generator().manual_seed(7 + r)) for r in range(world)]
+    ref = sum(t.to(torch.bfloat16).float() for t in inputs) / world
+    for _, a, b in res:
+        assert (abs(a - res[0][1]) == 0).all() and (abs(b - a) == 0).all()
+        assert float(abs(torch.from_numpy(a) - ref).max()) <= 2 ** -7 * float(ref.abs().max())
