@@ -11,7 +11,7 @@ from uda.model.regda_7 import PoseResNetx9
 from utils.synthetic import make_batch
 dev = torch.device('cuda:0'); mi355.load(); mi355.set_compute_dtype('bf16')
 torch.manual_seed(1)
-arch = os.environ.get('ARCH', 'resnet50'); S = 256; B = 64
+arch = os.environ.get('ARCH', 'resnet50'); S = int(os.environ.get('IMG', '256')); B = int(os.environ.get('BATCH', '64'))
 bb = models.__dict__[arch](pretrained=False)
 model = PoseResNetx9(bb, Upsampling(bb.out_features), 256, 21, num_head_layers=2, finetune=True).to(dev)
 step, opts, scheds = build_training(model, heatmap_size=S // 4)
@@ -29,9 +29,13 @@ o_fs, o_ds = ops.conv_fwd_stats, ops.conv_dgrad_stats
 def f4(desc, *a, **k): log[('fwd', key(desc))] += 1; return o_fs(desc, *a, **k)
 def f5(desc, *a, **k): log[('dgrad', key(desc))] += 1; return o_ds(desc, *a, **k)
 ops.conv_fwd_stats, ops.conv_dgrad_stats = f4, f5
+o_ma = ops.conv_dgrad_masked_acc
+def f6(desc, *a, **k): log[('dgrad', key(desc))] += 1; return o_ma(desc, *a, **k)
+ops.conv_dgrad_masked_acc = f6
 step.run(batch); torch.cuda.synchronize()
 ops.conv_fwd, ops.conv_dgrad, ops.conv_wgrad = o_f, o_d, o_w
 ops.conv_fwd_stats, ops.conv_dgrad_stats = o_fs, o_ds
+ops.conv_dgrad_masked_acc = o_ma
 del step, model, opts; torch.cuda.empty_cache()
 dt = torch.bfloat16
 def timeit(fn, n=10):
