@@ -1154,10 +1154,16 @@ static void launch_gather(GatherArgs& a, hipStream_t st) {
     if (even && (size_t)a.nphase * mx * a.Nout * 2 * sizeof(float) <= a.stat_bytes) a.stat_slices = a.nphase * mx;
     else a.bnb_partial = nullptr;
   }
-  constexpr bool EXTRAS = !HM_OUT && BM <= 128;     // the epilogue variants exist for the regular tiles only
-  if (!EXTRAS && (a.stat_partial || a.bnb_partial)) { a.stat_partial = nullptr; a.bnb_partial = nullptr; a.stat_slices = 0; }
+  constexpr bool EXTRAS = !HM_OUT && BM <= 128;     // the BatchNorm-backward epilogue exists for the regular tiles only
+  constexpr bool STATS = !HM_OUT && (BM <= 128 || (BM == 256 && BN == 128));   // statistics: also the 256x128 macro tile
+  if (!EXTRAS && a.bnb_partial) a.bnb_partial = nullptr;
+  static const bool stats256 = !(getenv("MI355_STATS_256") && atoi(getenv("MI355_STATS_256")) == 0);      // A/B switch
+  if ((!STATS || (BM == 256 && !stats256)) && a.stat_partial) { a.stat_partial = nullptr; a.stat_slices = 0; }
+  if (!a.stat_partial && !a.bnb_partial) a.stat_slices = 0;
   if constexpr (EXTRAS) {
     if (a.bnb_partial) { launch_gather_epi<T, BM, BN, SMALL_C, WGM, WGN, HM_OUT, DMA, 2>(a, st); return; }     // (EPI 2 has no KW3 build)
+  }
+  if constexpr (STATS) {
     if (a.stat_partial) { launch_gather_epi<T, BM, BN, SMALL_C, WGM, WGN, HM_OUT, DMA, 1, KW3>(a, st); return; }
   }
   launch_gather_epi<T, BM, BN, SMALL_C, WGM, WGN, HM_OUT, DMA, 0, KW3>(a, st);

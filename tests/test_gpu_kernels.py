@@ -164,6 +164,7 @@ STAT_CASES = [
     ('conv', 6, 64, 40, 40, 128, 1, 1, 0),     # 9600 rows: 128-row tiles
     ('conv', 20, 64, 64, 64, 128, 1, 1, 0),    # 81920 rows: >= 640 slices -> the block-per-channel finalize kernel
     ('deconv', 2, 256, 16, 16, 64, 4, 2, 1),   # four output phases in one launch
+    ('conv', 64, 64, 64, 64, 256, 3, 1, 1),    # 4096 output tiles: the 256x128 macro tile of the shared-A-tile kernel with the statistics epilogue
 ]
 
 
