@@ -658,6 +658,46 @@ __global__ __launch_bounds__(256) void apply_relu_mask_kernel(T* __restrict__ g,
   }
 }
 
+// Stem: BatchNorm + ReLU + MaxPool2d(3, 2, 1) in one pass (resnet.py:27-28 of the torchvision stem).  The normalised
+// 64-channel 128x128 map (134 MB at B=64) is never written: every window element is normalised on the fly (rounded to T as the
+// stand-alone apply pass would store it, so maxima and arg-max bytes are the same bit for bit), the backward recomputes the
+// ReLU mask from the conv output as for any BatchNorm without a residual.
+template <typename T>
+__global__ __launch_bounds__(256) void bn_relu_maxpool_kernel(const T* __restrict__ x, const float* __restrict__ scale_shift, T* __restrict__ y,
+                                                               uint8_t* __restrict__ arg, int N, int H, int W, int C, int Ho, int Wo) {
+  constexpr int CH = Chunk<T>::N;
+  const int cpr = C / CH;
+  const long total = (long)N * Ho * Wo * cpr;
+  for (long id = (long)blockIdx.x * 256 + threadIdx.x; id < total; id += (long)gridDim.x * 256) {
+    const int ch = (int)(id % cpr); long r = id / cpr;
+    const int ox = (int)(r % Wo); r /= Wo; const int oy = (int)(r % Ho); const int n = (int)(r / Ho);
+    float sc[CH], sh[CH], best[CH]; int bi[CH]; bool first = true;
+#pragma unroll
+    for (int e = 0; e < CH; ++e) { sc[e] = scale_shift[ch * CH + e]; sh[e] = scale_shift[C + ch * CH + e]; best[e] = -INFINITY; bi[e] = 0; }
+    for (int kh = 0; kh < 3; ++kh) {
+      const int iy = 2 * oy - 1 + kh; if (iy < 0 || iy >= H) continue;
+      for (int kw = 0; kw < 3; ++kw) {
+        const int ix = 2 * ox - 1 + kw; if (ix < 0 || ix >= W) continue;
+        float v[CH]; Chunk<T>::load(x + (((size_t)n * H + iy) * W + ix) * C + (size_t)ch * CH, v);
+        const int code = kh * 3 + kw;
+#pragma unroll
+        for (int e = 0; e < CH; ++e) {
+          float u = v[e] * sc[e] + sh[e];
+          u = u < 0.f ? 0.f : u;                           // keeps NaN
+          u = (float)(T)u;                                 // the value the apply pass would have stored
+          if (first) bi[e] = code;
+          if (u > best[e] || u != u) { best[e] = u; bi[e] = code; }
+        }
+        first = false;
+      }
+    }
+    const size_t o = (((size_t)n * Ho + oy) * Wo + ox) * C + (size_t)ch * CH;
+    Chunk<T>::store(y + o, best);
+#pragma unroll
+    for (int e = 0; e < CH; ++e) arg[o + e] = (uint8_t)bi[e];
+  }
+}
+
 __global__ __launch_bounds__(256) void colsum_finalize_kernel(const float* __restrict__ partial, int nslices, int C, float* out, int accumulate) {
   const int lane = threadIdx.x & 63;
   const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -745,6 +785,30 @@ extern "C" int mi355_bn_train_fwd_partials(const void* x, const void* residual, 
   else if (dtype == MI355_BF16) hipLaunchKernelGGL((bn_apply_kernel<bf16_t, false>), ga, dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)residual, (bf16_t*)y, (const float*)scale_shift, nf, nf, nf, nf, eps, rows, C, p.TX, relu, mk);
   else hipLaunchKernelGGL((bn_apply_kernel<float, false>), ga, dim3(256), 0, st, (const float*)x, (const float*)residual, (float*)y, (const float*)scale_shift, nf, nf, nf, nf, eps, rows, C, p.TX, relu, mk);
   MI_CHECK_LAUNCH("bn_train_fwd_partials");
+  return MI355_OK;
+}
+
+// mi355_bn_train_fwd_partials (statistics partials from the conv's epilogue) + ReLU + MaxPool2d(3, 2, 1): x [N][H][W][C] ->
+// y_pool [N][Ho][Wo][C] and the window-position bytes mi355_maxpool_bwd takes; the normalised map is not written.
+extern "C" int mi355_bn_relu_maxpool_fwd_partials(const void* x, void* y_pool, uint8_t* argidx, const float* gamma, const float* beta,
+                                                  float* running_mean, float* running_var, int64_t* nbt, float* save_mean,
+                                                  float* save_invstd, int N, int H, int W, int C, float eps, float momentum,
+                                                  int stat_updates, int dtype, const float* partial, int nslices, float* scale_shift,
+                                                  void* stream) {
+  const long rows = (long)N * H * W;
+  int CH; if (int e = bn_check(rows, C, dtype, &CH)) return e;
+  if (stat_updates < 0 || stat_updates > 8) MI_FAIL(MI355_EINVAL, "bn_relu_maxpool_fwd_partials: stat_updates=%d", stat_updates);
+  if (!partial || nslices < 1 || !scale_shift || !argidx || !y_pool) MI_FAIL(MI355_EINVAL, "bn_relu_maxpool_fwd_partials: null argument");
+  hipStream_t st = as_stream(stream);
+  static const int wide_min = getenv("MI355_BN_WIDE_FINALIZE") ? atoi(getenv("MI355_BN_WIDE_FINALIZE")) : 512;
+  if (nslices >= wide_min) hipLaunchKernelGGL(bn_finalize_wide_kernel, dim3(C), dim3(256), 0, st, partial, nslices, C, gamma, beta, running_mean, running_var, nbt, save_mean, save_invstd, scale_shift, eps, momentum, stat_updates);
+  else hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 4)), dim3(256), 0, st, partial, nslices, C, gamma, beta, running_mean, running_var, nbt, save_mean, save_invstd, scale_shift, eps, momentum, stat_updates);
+  const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+  const long total = (long)N * Ho * Wo * (C / CH);
+  int grid = (int)((total + 255) / 256); if (grid > 8192) grid = 8192;
+  if (dtype == MI355_BF16) hipLaunchKernelGGL(bn_relu_maxpool_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, (const bf16_t*)x, (const float*)scale_shift, (bf16_t*)y_pool, argidx, N, H, W, C, Ho, Wo);
+  else hipLaunchKernelGGL(bn_relu_maxpool_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)x, (const float*)scale_shift, (float*)y_pool, argidx, N, H, W, C, Ho, Wo);
+  MI_CHECK_LAUNCH("bn_relu_maxpool_fwd_partials");
   return MI355_OK;
 }
 

@@ -77,6 +77,7 @@ SIGNATURES = {
     'mi355_conv_dgrad_masked_acc': (_I, [_P, _P, _P, _P, _P, _P, _P]),
     'mi355_conv_fwd_act': (_I, [_P, _P, _P, _P, _P, _I, _P, _P]),
     'mi355_conv_dgrad_act': (_I, [_P, _P, _P, _P, _I, _P, _P]),
+    'mi355_bn_relu_maxpool_fwd_partials': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _F, _I, _I, _P, _I, _P, _P]),
     'mi355_maxpool_fwd': (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
     'mi355_maxpool_bwd': (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
     'mi355_nchw_to_nhwc': (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),

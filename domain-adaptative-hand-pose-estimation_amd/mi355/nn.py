@@ -119,6 +119,7 @@ def _as_feature(x, dtype):
 _LAZY_MASK = {}
 _LAZY_RES = _os.environ.get('MI355_BN_LAZY_DRES', '1') == '1'      # A/B switch
 _ZERO_BN_BIAS_GRAD = _os.environ.get('MI355_ZERO_BN_BIAS_GRAD', '1') == '1'      # A/B switch (see _bias_grad)
+_BN_POOL_FUSE = _os.environ.get('MI355_BN_POOL_FUSE', '1') == '1'      # A/B switch: stem BatchNorm + ReLU + max-pool in one pass
 
 
 def _take_lazy(g):
@@ -606,6 +607,35 @@ class _BnFn(torch.autograd.Function):
         return (dx if ctx.needs_input_grad[0] else None), None, None, dres, None, None, None, None
 
 
+class _BnReluPoolFn(torch.autograd.Function):
+    """Stem: BatchNorm2d (training, statistics from the conv epilogue) + ReLU + MaxPool2d(3, 2, 1) in one pass; the normalised
+    map is never written.  Backward: the pooled gradient is scattered by the stand-alone max-pool backward, then the one-launch
+    BatchNorm backward (ReLU mask recomputed from the conv output)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, mod, partial):
+        _BN_GEN[0] += 1
+        y, arg, mean, invstd = ops.bn_relu_maxpool_fwd(x, gamma, beta, mod.running_mean, mod.running_var, mod.num_batches_tracked,
+                                                       mod.eps, mod.momentum, _rt.bn_stat_updates, partial)
+        ctx.in_shape = tuple(x.shape)
+        ctx.save_for_backward(x, arg, mean, invstd, gamma, beta)
+        return y
+
+    @staticmethod
+    def backward(ctx, dpool):
+        x, arg, mean, invstd, gamma, beta = ctx.saved_tensors
+        dy = ops.maxpool_bwd(_as_grad(dpool, x.dtype), arg, ctx.in_shape)
+        dg = db = None
+        acc = False
+        if ctx.needs_input_grad[1]:
+            dg, acc = grad_slot(gamma)
+        if ctx.needs_input_grad[2]:
+            db, acc_b = grad_slot(beta)
+            acc = acc_b if dg is None else acc
+        dx, _ = ops.bn_bwd(dy, x, None, gamma, mean, invstd, dg, db, acc, True, False, beta=beta)
+        return (dx if ctx.needs_input_grad[0] else None), None, None, None, None
+
+
 class _MaxPoolFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x):
@@ -978,6 +1008,16 @@ class BatchNorm2d(nn.Module):
 
     def extra_repr(self):
         return '{num_features}, eps={eps}, momentum={momentum}'.format(num_features=self.num_features, eps=self.eps, momentum=self.momentum)
+
+    def forward_relu_maxpool(self, x, pool):
+        """pool(relu(bn(x))) for the stem: one fused pass in training mode when x carries the statistics of the conv that produced
+        it (and the fp8 side outputs are off); the three separate layers otherwise."""
+        dtype = compute_dtype()
+        tag = None if isinstance(x, _LazyConv) else getattr(x, '_mi_bn_partial', None)
+        if (_BN_POOL_FUSE and self.training and tag is not None and ops.is_nhwc(x) and x.dtype == dtype and x._version == tag[1] and
+                x.shape[1] == self.num_features and not (_FP8_BN_SIDE and _rt.fp8_convs()) and isinstance(pool, MaxPool2d)):
+            return _BnReluPoolFn.apply(x, self.weight, self.bias, self, tag[0])
+        return pool(self(x, relu=True))
 
     def forward(self, x, residual=None, relu=False):
         if isinstance(x, _LazyConv):

@@ -329,6 +329,24 @@ def bn_train_fwd(x, residual, gamma, beta, running_mean, running_var, nbt, eps, 
     return y, mean, invstd
 
 
+def bn_relu_maxpool_fwd(x, gamma, beta, running_mean, running_var, nbt, eps, momentum, stat_updates, partial):
+    """BatchNorm (train, statistics partials of the producing conv) + ReLU + MaxPool2d(3, 2, 1) in one pass; returns
+    (y_pool, argidx, mean, invstd)."""
+    _chk_dev(x, gamma)
+    N, C, H, W = x.shape
+    Ho, Wo = (H + 2 - 3) // 2 + 1, (W + 2 - 3) // 2 + 1
+    y = nhwc_empty(N, C, Ho, Wo, x.dtype, x.device)
+    arg = torch.empty((N, Ho, Wo, C), dtype=torch.uint8, device=x.device)
+    mean = torch.empty(C, dtype=torch.float32, device=x.device)
+    invstd = torch.empty(C, dtype=torch.float32, device=x.device)
+    ss = torch.empty(2 * C, dtype=torch.float32, device=x.device)
+    buf, ns = partial
+    call('mi355_bn_relu_maxpool_fwd_partials', ptr(x), ptr(y), ptr(arg), ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var),
+         ptr(nbt), ptr(mean), ptr(invstd), N, H, W, C, float(eps), float(momentum), int(stat_updates), dtype_code(x.dtype), ptr(buf),
+         int(ns), ptr(ss), stream_ptr())
+    return y, arg, mean, invstd
+
+
 def bn_eval_fwd(x, residual, gamma, beta, running_mean, running_var, eps, relu):
     _chk_dev(x, gamma)
     N, C, H, W = x.shape

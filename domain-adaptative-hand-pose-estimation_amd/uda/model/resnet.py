@@ -104,8 +104,7 @@ class ResNet(nn.Module):
         return nn.Sequential(*layers)
 
     def forward(self, x):
-        x = self.bn1(self.conv1(x), relu=True)
-        x = self.maxpool(x)
+        x = self.bn1.forward_relu_maxpool(self.conv1(x), self.maxpool)     # (training: one fused pass over the conv output)
         x = self.layer1(x)
         x = self.layer2(x)
         x = self.layer3(x)

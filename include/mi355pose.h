@@ -221,6 +221,15 @@ int mi355_bn_set_resident(int on);
  * UNMASKED dy on to the other branch (no dresidual write) together with its bit mask (mi355/nn.py _LAZY_MASK). */
 int mi355_apply_relu_mask(void* g, const void* relu_mask, long rows, int C, int dtype, void* stream);
 
+/* Stem: BatchNorm (statistics partials from the conv epilogue, as mi355_bn_train_fwd_partials) + ReLU + MaxPool2d(3, 2, 1) in
+ * one pass over the conv output: resnet.py:27-28 (`bn1`, `relu`, `maxpool` of the torchvision stem).  y_pool [N][Ho][Wo][C],
+ * argidx as mi355_maxpool_fwd writes it (its backward: mi355_maxpool_bwd, then mi355_bn_bwd with relu = 1 and y = NULL). */
+int mi355_bn_relu_maxpool_fwd_partials(const void* x, void* y_pool, uint8_t* argidx, const float* gamma, const float* beta,
+                                       float* running_mean, float* running_var, int64_t* nbt, float* save_mean,
+                                       float* save_invstd, int N, int H, int W, int C, float eps, float momentum,
+                                       int stat_updates, int dtype, const float* partial, int nslices, float* scale_shift,
+                                       void* stream);
+
 /* ---------------------------------------------------------------- stem max-pool 3x3 s2 p1
  * Replaces nn.MaxPool2d(3,2,1) of the torchvision stem (uda/model/resnet.py:28).  argidx: uint8 window
  * position (first maximum in (kh,kw) scan order, as ATen) kept for the backward gather. */

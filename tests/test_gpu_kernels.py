@@ -317,6 +317,34 @@ def test_bn_backward_one_launch_lds_resident(gpu, dt, shape, mode):
 
 
 @pytest.mark.parametrize('dt', ['f32', 'bf16'])
+@pytest.mark.parametrize('shape', [(2, 64, 32, 32), (3, 64, 18, 14)])
+def test_stem_batchnorm_relu_maxpool_in_one_pass(gpu, dt, shape):
+    """mi355_bn_relu_maxpool_fwd_partials == BatchNorm (conv-fused statistics) + ReLU, then MaxPool2d(3, 2, 1): pooled values,
+    arg-max bytes, saved statistics and running statistics bit for bit."""
+    ops = _ops()
+    N, C, H, W = shape
+    k, Ci = 3, 16
+    xin = _nhwc(_round(randn(91, N, Ci, H, W), dt), dt, gpu)
+    wm = (0.2 * randn(92, C, k, k, Ci)).to(gpu)
+    wf, _ = ops.pack_weights(wm, C, k * k, Ci, Ci, DT[dt])
+    desc = ops.make_desc(N, H, W, Ci, C, k, k, 1, 1, DT[dt])
+    y, part = ops.conv_fwd_stats(desc, xin, wf, None)
+    gamma, beta = (1 + 0.1 * randn(93, C)).to(gpu), (0.1 * randn(94, C)).to(gpu)
+    res = []
+    for fused in (False, True):
+        rm, rv = torch.zeros(C, device=gpu), torch.ones(C, device=gpu)
+        nbt = torch.zeros((), dtype=torch.int64, device=gpu)
+        if fused:
+            p, arg, mean, invstd = ops.bn_relu_maxpool_fwd(y, gamma, beta, rm, rv, nbt, 1e-5, 0.1, 1, part)
+        else:
+            z, mean, invstd = ops.bn_train_fwd(y, None, gamma, beta, rm, rv, nbt, 1e-5, 0.1, True, partial=part)
+            p, arg = ops.maxpool_fwd(z)
+        res.append((p, arg, mean, invstd, rm, rv, nbt))
+    for a, b in zip(*res):
+        assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize('dt', ['f32', 'bf16'])
 def test_maxpool_and_colsum(gpu, dt):
     ops = _ops()
     x = _round(randn(31, 2, 64, 18, 14), dt)
