@@ -269,11 +269,12 @@ class DAStep:
         has_t = b.get('label_t') is not None
         lab_t = ops.argmax2d(b['label_t'])[1] if has_t else None
         H, W = o['y_s'].shape[-2:]
+        from uda.model.regda_4 import cached_centres
         for name, pred, lab in (('s', o['y_s'], lab_s), ('t', o['y_t'], lab_t), ('s_adv', o['y_s_adv'], lab_s),
                                 ('t_adv', o['y_t_adv'], lab_t)):
             if lab is None:
                 continue
-            _, xy, _ = ops.argmax2d(pred)
+            xy = cached_centres(pred)            # (y_s / y_t: already computed for the pseudo-labels)
             o['pck_' + name] = ops.pck_dists(xy, lab, W / 10.0, H / 10.0)
 
     def _grads(self, keys):
@@ -291,6 +292,8 @@ class DAStep:
         """batch: dict x_s, label_s, w_s, x_t, w_t (+ optional label_t for the PCK bookkeeping)."""
         if self.graphs is not None:
             return self.replay(batch)
+        from uda.model.regda_4 import _CENTRES
+        _CENTRES.clear()
         self.model.train()
         self._begin_reduce(('f', 'h', 'h_adv', 'h_adv2', 'h_adv3'))
         self._fwdbwd_A(batch)
@@ -321,6 +324,8 @@ class DAStep:
                 self.run(self.static)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
+        from uda.model.regda_4 import _CENTRES
+        _CENTRES.clear()
         pool = torch.cuda.graph_pool_handle()
         segs = [lambda: self._fwdbwd_A(self.static), self._update_A, lambda: self._fwdbwd_B(self.static),
                 self._update_B, lambda: (self._fwdbwd_C(self.static)), lambda: (self._update_C(), self._accuracy(self.static))]

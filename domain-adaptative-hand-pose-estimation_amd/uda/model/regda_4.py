@@ -20,6 +20,25 @@ def gaussian_patch(tmp_size, sigma):
     return np.exp(- ((x - x0) ** 2 + (y - y0) ** 2) / (2 * sigma ** 2)).astype(np.float32)
 
 
+# arg-max coordinates of a prediction tensor are wanted by several consumers of one training step (three pseudo-label
+# generators per loss group, steps B and C on the same target prediction, the PCK bookkeeping): computed once per tensor.
+# An entry holds the tensor itself, so its address cannot be re-used while the entry lives; DAStep clears the table at the
+# start of every iteration (mi355/da_step.py).
+_CENTRES = {}
+
+
+def cached_centres(y):
+    y = y.detach()
+    key = (y.data_ptr(), y._version, tuple(y.shape))
+    ent = _CENTRES.get(key)
+    if ent is None or ent[0].dtype != y.dtype:
+        if len(_CENTRES) > 16:
+            _CENTRES.clear()
+        _, xy, _ = ops.argmax2d(y)
+        ent = _CENTRES[key] = (y, xy)
+    return ent[1]
+
+
 class _GaussianLabels(nn.Module):
     """Shared machinery: arg-max on the prediction, centre = trunc(xy / div), S x S label maps."""
 
@@ -32,8 +51,7 @@ class _GaussianLabels(nn.Module):
         self._patch_dev = {}
 
     def centres(self, y):
-        _, xy, _ = ops.argmax2d(y.detach())
-        return xy
+        return cached_centres(y)
 
     def labels(self, y, kind, extra=None, normalise=False, want_gt=True, want_gf=True, xy=None):
         if xy is None:
