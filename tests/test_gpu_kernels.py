@@ -154,6 +154,42 @@ def test_conv_dgrad_accumulates_onto_a_bit_masked_gradient(gpu, dt, case):
         ops.conv_dgrad_masked_acc(desc, dy, wt, base.clone(), None)
 
 
+@pytest.mark.parametrize('case', [CONV_CASES[0], CONV_CASES[1], CONV_CASES[5], CONV_CASES[9], CONV_CASES[16], CONV_CASES[17]])
+def test_conv_kernels_give_the_same_bits_run_after_run(gpu, case):
+    """Every epilogue form of the bf16 conv kernels twice on the same operands: forward (+bias, +residual, fused ReLU, fused
+    statistics), input gradient (plain, scaled accumulate, masked accumulate) and weight gradient must reproduce bit for bit.
+    Guards against timing-dependent faults: an earlier build of the masked accumulate dropped addends in a few lanes now and then
+    while every single-shot tolerance test passed (csrc/igemm.hip, epilogue comment)."""
+    ops = _ops()
+    N, Ci, H, W, Co, k, s, p = case
+    dt = torch.bfloat16
+    desc = ops.make_desc(N, H, W, Ci, Co, k, k, s, p, dt)
+    g = torch.Generator(device='cpu').manual_seed(1000 + Ci + Co + k)
+    wm = (torch.randn(Co, k, k, Ci, generator=g) * 0.05).to(gpu)
+    wf, wt = ops.pack_weights(wm, Co, k * k, Ci, Ci, dt)
+    x = ops.nhwc_empty(N, Ci, H, W, dt, gpu).normal_()
+    dy = ops.nhwc_empty(N, Co, desc.Ho, desc.Wo, dt, gpu).normal_()
+    res = ops.nhwc_empty(N, Co, desc.Ho, desc.Wo, dt, gpu).normal_()
+    base = ops.nhwc_empty(N, Ci, H, W, dt, gpu).normal_()
+    bias = torch.randn(Co, generator=g).to(gpu)
+    mask = torch.randint(0, 256, (N * H * W * Ci // 8,), dtype=torch.uint8, device=gpu)
+    sc = torch.tensor(0.25, device=gpu)
+    dw = torch.zeros(Co, k, k, Ci, device=gpu)
+
+    def once():
+        out = [ops.conv_fwd(desc, x, wf, bias), ops.conv_fwd(desc, x, wf, bias, res), ops.conv_fwd(desc, x, wf, bias, res, relu=True)]
+        y, part = ops.conv_fwd_stats(desc, x, wf, None)
+        out += [y, part[0][:part[1] * Co * 3].clone()]
+        out += [ops.conv_dgrad(desc, dy, wt), ops.conv_dgrad(desc, dy, wt, scale_dev=sc, out=base.clone(), accumulate=True),
+                ops.conv_dgrad_masked_acc(desc, dy, wt, base.clone(), mask)]
+        ops.conv_wgrad(desc, x, dy, dw, accumulate=False)
+        out.append(dw.clone())
+        return out
+    a, b = once(), once()
+    for i, (u, v) in enumerate(zip(a, b)):
+        assert torch.equal(u, v), 'output %d differs between two runs' % i
+
+
 STAT_CASES = [
     # kind, N, Ci, H, W, Co, k, s, p   (kind 'conv': Conv2d; 'deconv': conv-form of ConvTranspose2d(Co -> Ci, 4, 2, 1))
     ('conv', 2, 64, 16, 16, 128, 3, 1, 1),
