@@ -338,6 +338,10 @@ def test_bn_backward_one_launch_lds_resident(gpu, dt, shape, mode):
     y, mean, invstd = ops.bn_train_fwd(xd, to(r) if res else None, gamma, beta, rm, rv, nbt, 1e-5, 0.1, relu, relu_mask=mask)
     dg = torch.full((C,), 0.5, device=gpu); db = torch.full((C,), -0.25, device=gpu)
     dx, dres = ops.bn_bwd(dyd, xd, None, gamma, mean, invstd, dg, db, True, relu, res, beta=beta, relu_mask=mask)
+    # the in-launch exchange folds the blocks' partial sums in a fixed order: a second run reproduces every bit
+    dg2 = torch.full((C,), 0.5, device=gpu); db2 = torch.full((C,), -0.25, device=gpu)
+    dx2, dres2 = ops.bn_bwd(dyd, xd, None, gamma, mean, invstd, dg2, db2, True, relu, res, beta=beta, relu_mask=mask)
+    assert torch.equal(dx2, dx) and torch.equal(dg2, dg) and torch.equal(db2, db) and (dres is None or torch.equal(dres2, dres))
     scale = float(xr.grad.abs().max()) + 1e-6
     # fp32: the forward's y = x*sc+sh may round a value next to zero to the other side of the ReLU than torch's formula does
     err = (dx.float() - xr.grad).abs()
