@@ -443,34 +443,47 @@ struct BnResArgs {
   void* dx; void* dres; float* dgamma; float* dbeta; const unsigned char* mask;
   float* partial;                       // [G][R][2 * channels per group]
   long rows; int C, G, R, rpb, keep, accumulate; float inv_rows;      // keep: rows of a block's tile that stay in LDS
+  unsigned spin_limit;                  // grid-barrier poll iterations before a block gives up (and poisons its outputs)
 };
-// One arrival counter per grid size, never reset: a launch of n blocks moves it from one multiple of n to the next, so a
-// block that drew ticket v waits for the counter to reach (v / n + 1) * n (wrap-safe compare).  Launches of this kernel on
-// one device must not overlap in time (this library issues them on one stream; MI355_BN_RESIDENT=0 otherwise).
+// One 64-bit arrival counter per grid size, never reset: a launch of n blocks moves it from one multiple of n to the next, so
+// a block that drew ticket v waits for the counter to reach (v / n + 1) * n (64 bits: no wrap within the life of a process;
+// the 32-bit form would have wrapped after ~1e5 training iterations and broken every grid size that is not a power of two).
+// Launches of this kernel on one device must not overlap in time (this library issues them on one stream;
+// MI355_BN_RESIDENT=0 otherwise).  A block whose spin gives up (a co-resident kernel kept one of the grid's blocks off the chip
+// for longer than the limit) FAILS LOUDLY: it counts the event in bn_res_err[0] (sticky until mi355_bn_resident_reset) and
+// poisons everything it writes -- its dx rows, and dgamma / dbeta if it owns them -- with NaN instead of continuing on
+// incomplete sums; the host side raises on the counter (mi355.ops.bn_resident_check: train1.py once per epoch, DAStep.check_health,
+// bench.py, smoke).
 #define BN_RES_MAXBLK 1024
 #define BN_RES_KR 0        // tile rows per thread held in registers (8 VGPRs each)
 #define BN_RES_NT 1024     // threads per block
-__device__ unsigned bn_res_sync[BN_RES_MAXBLK + 4];     // [n] arrivals of the n-block launches; [0]: spins that gave up
+__device__ unsigned long long bn_res_sync[BN_RES_MAXBLK + 1];     // [n] arrivals of the n-block launches
+__device__ unsigned bn_res_err[4];                                // [0]: spins that gave up since load / reset
 
-__device__ __forceinline__ void bn_res_grid_barrier(unsigned nblk, int t) {
+// returns false (in every thread of the block) when the spin gave up
+__device__ __forceinline__ bool bn_res_grid_barrier(unsigned nblk, int t, unsigned spin_limit, int* ok_lds) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every wave: its sc1 partial stores have left
   __syncthreads();
   if (t == 0) {
-    unsigned* st = bn_res_sync + nblk;
-    const unsigned v = __hip_atomic_fetch_add(st, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const unsigned target = (v / nblk + 1u) * nblk;
-    if (v + 1u != target) {               // (the last arriver has nothing to wait for)
+    int ok = 1;
+    unsigned long long* st = bn_res_sync + nblk;
+    const unsigned long long v = __hip_atomic_fetch_add(st, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long target = (v / nblk + 1ull) * nblk;
+    if (v + 1ull != target) {             // (the last arriver has nothing to wait for)
       unsigned spins = 0;
-      while ((int)(__hip_atomic_load(st, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
+      while (__hip_atomic_load(st, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
         __builtin_amdgcn_s_sleep(4);
-        if (++spins > (1u << 19)) {       // ~0.3 s: a block that never became resident -- give up (results invalid, counted)
-          __hip_atomic_fetch_add(bn_res_sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (++spins > spin_limit) {       // default ~0.3 s: a block that never became resident
+          __hip_atomic_fetch_add(bn_res_err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          ok = 0;
           break;
         }
       }
     }
+    *ok_lds = ok;
   }
   __syncthreads();
+  return *ok_lds != 0;
 }
 
 // A block's tile, by row: the first KR * NT / 8 rows live in REGISTERS (row ty + k NT / 8 in slot k of its thread), the
@@ -491,6 +504,7 @@ __global__ __launch_bounds__(NT) void bn_bwd_resident_kernel(BnResArgs p) {
   uint4* ds = xs + (size_t)keep * 8;
   float* red = reinterpret_cast<float*>(ds + (size_t)keep * 8);      // [NW][GC][2], later [NL][GC*2]
   float* tot = red + NW * GC * 2;                                    // [GC*2]
+  int* bar_ok = reinterpret_cast<int*>(tot + GC * 2);                // the grid barrier's verdict, broadcast to the block
   const T* __restrict__ X = reinterpret_cast<const T*>(p.x);
   const T* __restrict__ DY = reinterpret_cast<const T*>(p.dy);
   const int C = p.C, cpr = C / CH, c0 = g * GC + tx * CH, chunk = c0 / CH;
@@ -565,7 +579,7 @@ __global__ __launch_bounds__(NT) void bn_bwd_resident_kernel(BnResArgs p) {
     for (int w = 0; w < NW; ++w) a += red[w * GC * 2 + t];
     __hip_atomic_store(part + (size_t)r * (GC * 2) + t, a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // sc1: write-through
   }
-  bn_res_grid_barrier((unsigned)(p.G * p.R), t);
+  const bool exchanged = bn_res_grid_barrier((unsigned)(p.G * p.R), t, p.spin_limit, bar_ok);
   // ---- the group's totals: NL lanes per value over the R blocks (fixed order), then the lanes in order
   {
     // sc1 buffer loads (aux 16), eight in flight per thread: atomic loads would be waited for one at a time
@@ -594,7 +608,11 @@ __global__ __launch_bounds__(NT) void bn_bwd_resident_kernel(BnResArgs p) {
   __syncthreads();
   float k1[CH], k2[CH];
 #pragma unroll
-  for (int e = 0; e < CH; ++e) { s1[e] = tot[(tx * CH + e) * 2]; s2[e] = tot[(tx * CH + e) * 2 + 1]; k1[e] = s1[e] * p.inv_rows; k2[e] = s2[e] * p.inv_rows; }
+  for (int e = 0; e < CH; ++e) {
+    s1[e] = tot[(tx * CH + e) * 2]; s2[e] = tot[(tx * CH + e) * 2 + 1];
+    if (!exchanged) { s1[e] = __builtin_nanf(""); s2[e] = __builtin_nanf(""); }      // incomplete sums must not pass for a gradient
+    k1[e] = s1[e] * p.inv_rows; k2[e] = s2[e] * p.inv_rows;
+  }
   if (r == 0 && ty == 0) {
 #pragma unroll
     for (int e = 0; e < CH; ++e) {
@@ -827,7 +845,7 @@ extern "C" int mi355_bn_eval_fwd(const void* x, const void* residual, void* y, c
 }
 
 // ---- resident backward: plan + launch (returns false when the tensor does not fit / the mode is not covered)
-struct BnResPlan { int G, R, rpb, keep; size_t lds; };
+struct BnResPlan { int G, R, rpb, keep; size_t lds, max_lds; };
 static int g_bn_resident = -1;       // run-time switch (mi355_bn_set_resident); -1: the environment decides
 // The one-launch backward needs every block resident at once.  A caller that runs other kernels BESIDE the backward on the same
 // device (a collective overlapped with it: mi355/da_step.py) switches it off for that stretch: a CU held by the other kernel
@@ -847,7 +865,7 @@ static bool bn_resident_plan(long rows, int C, int CH, BnResPlan* q) {
     if (hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) != hipSuccess) return false;
     max_lds = (size_t)v;
     if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return false;
-    ncu = v;
+    ncu = v > 256 ? 256 : v;      // mi355_bn_workspace reserves partials for at most 256 blocks x 64 channels x 2 sums
   }
   const int GC = 8 * CH;
   if (C % GC) return false;
@@ -860,33 +878,54 @@ static bool bn_resident_plan(long rows, int C, int CH, BnResPlan* q) {
   q->R = (int)((rows + q->rpb - 1) / q->rpb);
   static const long max_bytes = getenv("MI355_BN_RESIDENT_MAX") ? atol(getenv("MI355_BN_RESIDENT_MAX")) : (1L << 62);
   if (rows * C * (16 / CH) > max_bytes) return false;
-  const size_t scratch = (size_t)(BN_RES_NT / 64 * GC * 2 + GC * 2) * sizeof(float);
+  const size_t scratch = (size_t)(BN_RES_NT / 64 * GC * 2 + GC * 2 + 4) * sizeof(float);      // sums, totals, barrier verdict
   long keep = (long)((max_lds - scratch) / 256);        // tile rows (128 B of x + 128 B of dy each) that fit beside the scratch
   const long reg_rows = (long)BN_RES_KR * (BN_RES_NT / 8);
   const long rest = q->rpb > reg_rows ? q->rpb - reg_rows : 0;
   if (keep > rest) keep = rest;
   q->keep = (int)keep;
   q->lds = (size_t)keep * 256 + scratch;
+  q->max_lds = max_lds;
   return (size_t)q->G * q->R <= (size_t)ncu && q->G * q->R <= BN_RES_MAXBLK;
 }
+static unsigned g_bn_res_spin = 1u << 19;      // grid-barrier poll iterations (~0.3 s) before a block gives up
+// Test hook: shrink (or restore, 0 = default) the spin bound so that a give-up can be provoked on purpose.
+extern "C" int mi355_bn_resident_set_spin_limit(unsigned limit) {
+  g_bn_res_spin = limit ? limit : (1u << 19);
+  return MI355_OK;
+}
+#define BN_RES_NOT_RESIDENT 1      // (internal) the kernel cannot hold one block per CU: take the three-launch form
 template <typename T, int RELU>
-static int bn_resident_launch(const BnResArgs& a, size_t lds, hipStream_t st) {
-  static size_t raised = 0;
+static int bn_resident_launch(const BnResArgs& a, size_t lds, size_t max_lds, hipStream_t st) {
+  static int fits = -1;      // does one block of this variant fit a CU at the largest LDS size the plan may ask for?
   auto kern = bn_bwd_resident_kernel<T, RELU, BN_RES_KR, BN_RES_NT>;
-  if (lds > raised) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-      MI_FAIL(MI355_ELAUNCH, "bn_bwd: cannot raise the dynamic LDS limit to %zu bytes", lds);
-    raised = lds;
+  if (fits < 0) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)max_lds) != hipSuccess)
+      MI_FAIL(MI355_ELAUNCH, "bn_bwd: cannot raise the dynamic LDS limit to %zu bytes", max_lds);
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, BN_RES_NT, max_lds) != hipSuccess) nb = 0;
+    fits = nb >= 1 ? 1 : 0;
   }
+  if (!fits) return BN_RES_NOT_RESIDENT;
   hipLaunchKernelGGL(kern, dim3(a.G * a.R), dim3(BN_RES_NT), lds, st, a);
   return MI355_OK;
 }
-// number of grid-barrier spins that gave up since the library was loaded (0 unless a block never became resident); synchronises
+// Number of grid-barrier spins that gave up since the library was loaded or mi355_bn_resident_reset (0 unless a block of a
+// one-launch backward was kept off the chip).  Every such launch has poisoned its outputs with NaN.  Synchronises the device.
 extern "C" int mi355_bn_resident_timeouts(unsigned* out) {
   unsigned v[4] = {0, 0, 0, 0};
   if (!out) MI_FAIL(MI355_EINVAL, "bn_resident_timeouts: out is null");
-  if (hipMemcpyFromSymbol(v, HIP_SYMBOL(bn_res_sync), sizeof(v)) != hipSuccess) MI_FAIL(MI355_ELAUNCH, "bn_resident_timeouts: copy failed");
+  if (hipMemcpyFromSymbol(v, HIP_SYMBOL(bn_res_err), sizeof(v)) != hipSuccess) MI_FAIL(MI355_ELAUNCH, "bn_resident_timeouts: copy failed");
   *out = v[0];
+  return MI355_OK;
+}
+// Clears the give-up count and the arrival counters (after a give-up has been reported and handled).  Synchronises the device.
+extern "C" int mi355_bn_resident_reset(void) {
+  static const unsigned long long zeros[BN_RES_MAXBLK + 1] = {0};
+  static const unsigned zerr[4] = {0, 0, 0, 0};
+  if (hipDeviceSynchronize() != hipSuccess) MI_FAIL(MI355_ELAUNCH, "bn_resident_reset: device synchronize failed");
+  if (hipMemcpyToSymbol(HIP_SYMBOL(bn_res_sync), zeros, sizeof(zeros)) != hipSuccess ||
+      hipMemcpyToSymbol(HIP_SYMBOL(bn_res_err), zerr, sizeof(zerr)) != hipSuccess) MI_FAIL(MI355_ELAUNCH, "bn_resident_reset: copy failed");
   return MI355_OK;
 }
 
@@ -917,16 +956,17 @@ extern "C" int mi355_bn_bwd(const void* dy, const void* x, const void* y, const 
   hipStream_t st = as_stream(stream);
   BnResPlan rp;
   if (relu != 1 && !q8_out && bn_resident_plan(rows, C, CH, &rp)) {
+    if (ws_bytes < (size_t)rp.G * rp.R * (8 * CH) * 2 * sizeof(float)) MI_FAIL(MI355_EWORKSPACE, "bn_bwd: workspace too small for the one-launch partials");
     BnResArgs a;
     a.dy = dy; a.x = x; a.mean = save_mean; a.invstd = save_invstd; a.gamma = gamma; a.beta = beta; a.dx = dx; a.dres = dresidual;
     a.dgamma = dgamma; a.dbeta = dbeta; a.mask = mk; a.partial = reinterpret_cast<float*>(ws); a.rows = rows; a.C = C;
     a.G = rp.G; a.R = rp.R; a.rpb = rp.rpb; a.keep = rp.keep; a.accumulate = accumulate; a.inv_rows = 1.0f / (float)rows;
+    a.spin_limit = g_bn_res_spin;
     int e;
-    if (dtype == MI355_BF16) e = relu == 0 ? bn_resident_launch<bf16_t, 0>(a, rp.lds, st) : relu == 2 ? bn_resident_launch<bf16_t, 2>(a, rp.lds, st) : bn_resident_launch<bf16_t, 3>(a, rp.lds, st);
-    else e = relu == 0 ? bn_resident_launch<float, 0>(a, rp.lds, st) : relu == 2 ? bn_resident_launch<float, 2>(a, rp.lds, st) : bn_resident_launch<float, 3>(a, rp.lds, st);
-    if (e) return e;
-    MI_CHECK_LAUNCH("bn_bwd (resident)");
-    return MI355_OK;
+    if (dtype == MI355_BF16) e = relu == 0 ? bn_resident_launch<bf16_t, 0>(a, rp.lds, rp.max_lds, st) : relu == 2 ? bn_resident_launch<bf16_t, 2>(a, rp.lds, rp.max_lds, st) : bn_resident_launch<bf16_t, 3>(a, rp.lds, rp.max_lds, st);
+    else e = relu == 0 ? bn_resident_launch<float, 0>(a, rp.lds, rp.max_lds, st) : relu == 2 ? bn_resident_launch<float, 2>(a, rp.lds, rp.max_lds, st) : bn_resident_launch<float, 3>(a, rp.lds, rp.max_lds, st);
+    if (e == MI355_OK) { MI_CHECK_LAUNCH("bn_bwd (resident)"); return MI355_OK; }
+    if (e != BN_RES_NOT_RESIDENT) return e;
   }
   BnPlan p = bn_plan(rows, C, CH, bwd_slices());
   float* partial = reinterpret_cast<float*>(ws);

@@ -1630,8 +1630,14 @@ extern "C" size_t mi355_conv_wgrad_grouped_workspace(const mi355_wgrad_item* ite
     bool flush = (i == n) || m == WG_MAX;
     if (i < n) {
       WgradPlan w = plan_wgrad(&items[i].d);
-      if (!group_eligible(&items[i].d, w)) { size_t b = mi355_conv_wgrad_workspace(&items[i].d); if (b > need) need = b; continue; }
-      if (m && items[idx[0]].d.dtype != items[i].d.dtype) flush = true;
+      bool shares = false;       // (same grouping as mi355_conv_wgrad_grouped: an item whose dw is already pending closes the group)
+      for (int k = 0; k < m; ++k) shares = shares || items[idx[k]].dw == items[i].dw;
+      if (!group_eligible(&items[i].d, w)) {
+        size_t b = mi355_conv_wgrad_workspace(&items[i].d); if (b > need) need = b;
+        if (!shares) continue;
+        flush = true;
+      }
+      if (m && (items[idx[0]].d.dtype != items[i].d.dtype || shares)) flush = true;
     }
     if (flush && m) { size_t b = 0; group_plan(items, idx, m, gp, &b); if (b > need) need = b; m = 0; }
     if (i < n && group_eligible(&items[i].d, plan_wgrad(&items[i].d))) idx[m++] = i;
@@ -1692,6 +1698,11 @@ extern "C" int mi355_conv_wgrad_grouped(const mi355_wgrad_item* items, int n, vo
     if (int e = check_desc(&it.d)) return e;
     if (!it.x || !it.dy || !it.dw) MI_FAIL(MI355_EINVAL, "wgrad_grouped: item %d has a null operand", i);
     WgradPlan w = plan_wgrad(&it.d);
+    // Two items that write the same dw (one conv used twice in a backward: overwrite, then accumulate) must neither share a
+    // launch -- the overwrite and the read-modify-write would race -- nor change their order: whatever is pending goes first.
+    bool shares = false;
+    for (int k = 0; k < m; ++k) shares = shares || items[idx[k]].dw == it.dw;
+    if (shares) { if (int e = launch_wgrad_group(items, idx, m, ws, ws_bytes, st)) return e; m = 0; }
     if (!group_eligible(&it.d, w)) {
       if (int e = mi355_conv_wgrad(&it.d, it.x, it.dy, it.dw, it.accumulate, ws, ws_bytes, stream)) return e;
       continue;

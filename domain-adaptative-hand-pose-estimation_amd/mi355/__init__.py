@@ -11,7 +11,9 @@ import torch
 
 F32, BF16, FP8 = 0, 1, 2
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), 'libmi355pose.so')
+# MI355_LIB: load another build of the same library instead (A/B runs of compiler flags: build.py --variant; the bisection
+# builds of profiles/dropped_addend_repro.py) -- an experiment switch, unset in normal use
+LIB_PATH = os.environ.get('MI355_LIB') or os.path.join(os.path.dirname(_HERE), 'libmi355pose.so')
 
 _lib = None
 _lock = threading.Lock()
@@ -72,6 +74,8 @@ SIGNATURES = {
     'mi355_bn_bwd_partials': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _L, _I, _I, _I, _P, _I, _P, _P, _P, _P, _P]),
     'mi355_bn_bwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _L, _I, _I, _I, _P, _Z, _P, _P, _P, _P]),
     'mi355_bn_resident_timeouts': (_I, [_P]),
+    'mi355_bn_resident_reset': (_I, []),
+    'mi355_bn_resident_set_spin_limit': (_I, [ctypes.c_uint]),
     'mi355_bn_set_resident': (_I, [_I]),
     'mi355_apply_relu_mask': (_I, [_P, _P, _L, _I, _I, _P]),
     'mi355_conv_dgrad_masked_acc': (_I, [_P, _P, _P, _P, _P, _P, _P]),

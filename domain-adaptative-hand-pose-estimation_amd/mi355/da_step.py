@@ -287,6 +287,12 @@ class DAStep:
                 bufs += [p.grad for g in o.param_groups for p in g['params'] if p.grad is not None]
         return bufs
 
+    def check_health(self, where=''):
+        """Raise if any kernel of the steps run so far reported an in-launch failure (today: a one-launch BatchNorm backward
+        that gave up waiting for its blocks and poisoned its gradients).  Synchronises the device."""
+        from . import ops
+        ops.bn_resident_check(where)
+
     # ------------------------------------------------------------------ eager iteration
     def run(self, batch):
         """batch: dict x_s, label_s, w_s, x_t, w_t (+ optional label_t for the PCK bookkeeping)."""

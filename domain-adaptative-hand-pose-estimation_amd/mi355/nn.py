@@ -39,6 +39,7 @@ def mark_grads_fresh(params):
             p._mi_fresh = True
     _BWD_PARTIALS.clear()          # leftovers of a backward pass that never reached their BatchNorm
     _LAZY_MASK.clear()
+    _BN_DX.clear()
     _GRAD_Q8.clear()               # ... or whose fp8 gradient copy no conv picked up
 
 
@@ -312,6 +313,9 @@ _FP8_BN_SIDE = _os.environ.get('MI355_FP8_BN_SIDE', '0') == '1'   # A/B switch: 
 # dy tensors whose producing GEMM already reduced them for the BatchNorm backward: data_ptr -> (dy, (partial, nslices)).
 # The entry keeps dy alive, so its address cannot be reused while the entry exists; BatchNorm's backward pops it.
 _BWD_PARTIALS = {}
+# input gradients written by a BatchNorm backward whose input came from one of our biased convs (address -> tensor; the entry
+# keeps the tensor alive until that conv's backward has looked it up, so the address cannot be reused meanwhile): see _bias_grad
+_BN_DX = {}
 
 
 def _bn_src_of(x):
@@ -377,7 +381,11 @@ def _bias_grad(ctx, bias, dy):
     in exact arithmetic (sum xhat = 0): the reference's value there is rounding noise around zero; zero is written instead of
     running the reduction (19 of the 23 column sums of an iteration)."""
     g, acc = grad_slot(bias)
-    if getattr(ctx, 'bias_grad_zero', False) and _ZERO_BN_BIAS_GRAD:
+    # ... which only holds when dy IS that BatchNorm's input gradient: a conv output that also fed another consumer (a skip
+    # connection, an auxiliary loss) receives the sum of several gradients -- a different tensor, not in _BN_DX -> column sum
+    ent = _BN_DX.pop(dy.data_ptr(), None)
+    from_bn = ent is not None and ent.shape == dy.shape and ent.dtype == dy.dtype
+    if getattr(ctx, 'bias_grad_zero', False) and from_bn and _ZERO_BN_BIAS_GRAD:
         if not acc:
             g.zero_()
         return
@@ -544,7 +552,8 @@ class _DeconvFn(torch.autograd.Function):
 
 class _BnFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, gamma, beta, residual, mod, relu, partial=None, lazy_ok=False):
+    def forward(ctx, x, gamma, beta, residual, mod, relu, partial=None, lazy_ok=False, tag_dx=False):
+        ctx.tag_dx = bool(tag_dx)
         # 'fp8' mode: the e4m3 copy of y for the fp8 conv that consumes it is written by the apply pass itself (delayed scale);
         # the very first tensor of the stream is scaled just in time by a stand-alone pass instead
         q8 = None
@@ -600,11 +609,13 @@ class _BnFn(torch.autograd.Function):
         if hand_on:            # the identity branch gets dy itself; its consumer applies the bit mask (see _LAZY_MASK)
             dres = dy
             _LAZY_MASK[dy.data_ptr()] = (dy, ctx.mask)
+        if ctx.tag_dx and ctx.needs_input_grad[0]:
+            _BN_DX[dx.data_ptr()] = dx
         if emit:       # e5m2 copy of dx for the fp8 input-gradient GEMM of the conv in front (found again by address)
             if q8 is None:
                 q8 = stream.quantize(dx)
             _GRAD_Q8[dx.data_ptr()] = (dx, q8[0], q8[1], ops.E5M2, dx._version)
-        return (dx if ctx.needs_input_grad[0] else None), None, None, dres, None, None, None, None
+        return (dx if ctx.needs_input_grad[0] else None), None, None, dres, None, None, None, None, None
 
 
 class _BnReluPoolFn(torch.autograd.Function):
@@ -1028,6 +1039,7 @@ class BatchNorm2d(nn.Module):
         if self.training:
             tag = getattr(x, '_mi_bn_partial', None)          # statistics partials from the conv that produced x
             partial = None
+            tag_dx = False
             if tag is not None:
                 partial, ver, cctx = tag
                 if x._version != ver:
@@ -1037,11 +1049,12 @@ class BatchNorm2d(nn.Module):
                     partial = None
                 elif cctx is not None:
                     cctx.bias_grad_zero = True      # (see _bias_grad)
+                    tag_dx = bool(getattr(cctx, 'has_bias', False))
             # the identity branch's gradient may be handed on unmasked when its producer is one of ours that knows how to apply
             # the mask: conv1.forward_skip's alias of the block input, or the downsample BatchNorm
             fn = getattr(residual, 'grad_fn', None) if residual is not None else None
             lazy_ok = fn is not None and type(fn).__name__ in ('_ConvSkipFnBackward', '_BnFnBackward')
-            y = _BnFn.apply(x, self.weight, self.bias, residual, self, bool(relu), partial, lazy_ok)
+            y = _BnFn.apply(x, self.weight, self.bias, residual, self, bool(relu), partial, lazy_ok, tag_dx)
             y._mi_bn_src, self._last_src = self._last_src, None     # lets the consumer conv's dgrad reduce dy for this BN
             q8, self._last_q8 = self._last_q8, None
             if q8 == 'jit':

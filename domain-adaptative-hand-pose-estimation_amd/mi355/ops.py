@@ -382,10 +382,34 @@ def bn_bwd(dy, x, y, gamma, mean, invstd, dgamma, dbeta, accumulate, relu, want_
 
 # ---------------------------------------------------------------- max pool
 def bn_resident_timeouts():
-    """Grid-barrier spins of the one-launch BatchNorm backward that gave up since the library was loaded (0 = healthy)."""
+    """Grid-barrier spins of the one-launch BatchNorm backward that gave up since the library was loaded or the last reset
+    (0 = healthy).  Every such launch has written NaN into the gradients it produced.  Synchronises the device."""
     n = ctypes.c_uint(0)
     call('mi355_bn_resident_timeouts', ctypes.byref(n))
     return n.value
+
+
+def bn_resident_reset():
+    call('mi355_bn_resident_reset')
+
+
+def bn_resident_set_spin_limit(limit):
+    """Test hook: poll iterations before a block of the one-launch BatchNorm backward gives up (0 = default)."""
+    call('mi355_bn_resident_set_spin_limit', int(limit))
+
+
+def bn_resident_check(where=''):
+    """Raise when a one-launch BatchNorm backward could not get all its blocks onto the chip since the last check: its gradients
+    are NaN (csrc/bn.hip bn_res_grid_barrier).  The one-launch form is switched off for the rest of the process and the counters
+    are cleared, so a caller that catches the error can redo the step on the three-launch path.  Synchronises the device: call it
+    where the host waits anyway (train1.py: once per epoch; bench.py / smoke: at the end)."""
+    n = bn_resident_timeouts()
+    if n:
+        load().mi355_bn_set_resident(0)
+        bn_resident_reset()
+        raise Mi355Error('%d grid-barrier give-up(s) in the one-launch BatchNorm backward%s: another kernel or process held CUs while '
+                         'it ran, the gradients of those launches are NaN.  The one-launch form is now off for this process '
+                         '(MI355_BN_RESIDENT=0 makes that the default); redo the affected steps.' % (n, (' (' + where + ')') if where else ''))
 
 
 def maxpool_fwd(x):

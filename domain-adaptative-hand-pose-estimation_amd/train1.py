@@ -38,6 +38,7 @@ from torch.utils.data.distributed import DistributedSampler
 
 import mi355
 import uda.model as models
+from mi355 import ops as _ops
 from mi355.da_step import build_training, broadcast_module, _allreduce_mean
 from mi355.optim import FusedSGD
 from uda.model.loss import JointsKLLoss
@@ -178,6 +179,7 @@ def main(args):
                 lr_scheduler.step()                      # the reference steps the schedule before the epoch (train1.py:167)
                 pretrain(train_source_iter, pre, criterion, optimizer, epoch, args)
                 acc = validate(val_source_loader, pre, criterion, args)
+                _ops.bn_resident_check('pre-training epoch %d' % epoch)   # (validation has synchronised: the poll is free)
                 if acc['all'] > best_acc:
                     best_acc = acc['all']
                     if RANK == 0:
@@ -220,6 +222,9 @@ def main(args):
         train(train_source_iter, train_target_iter, step, scheds, epoch, args)
         s_acc = validate(val_source_loader, model, criterion, args)
         t_acc = validate(val_target_loader, model, criterion, args)
+        # a one-launch BatchNorm backward whose blocks could not all get onto the chip has written NaN gradients: raise
+        # instead of training on (the poll synchronises, validation just has)
+        step.check_health('epoch %d' % epoch)
         if WORLD > 1:
             print('replicas in sync (parameter checksum %.6e)' % replicas_in_sync(model))
         if RANK != 0:

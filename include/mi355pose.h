@@ -207,14 +207,23 @@ int mi355_bn_bwd(const void* dy, const void* x, const void* y, const float* gamm
 /* mi355_bn_bwd takes ONE launch when x and dy fit the chip's LDS together (<= ~16.8 MB each on 256 CUs), C is a multiple of
  * 64 (bf16) / 32 (fp32) and the mask does not come from y: each CU keeps its tile of both tensors in LDS between the
  * reduction and the apply pass (3 tensor passes over HBM instead of 5); the blocks exchange their partial sums inside the
- * launch behind a bounded spin.  MI355_BN_RESIDENT=0 keeps the three-launch form.  *out = spins that gave up since the
- * library was loaded (0 unless a block could not become resident; the results of such a launch are invalid). Synchronises. */
+ * launch behind a bounded spin.  MI355_BN_RESIDENT=0 keeps the three-launch form.  The one-launch form is only taken when the
+ * occupancy query admits one block per CU at the largest LDS size (else the three-launch form runs).  A block whose spin
+ * gives up (~0.3 s: another kernel kept a block of the grid off the chip) FAILS LOUDLY: it writes NaN into its rows of dx
+ * (and dgamma / dbeta if it owns them) and counts the event.  *out = give-ups since the library was loaded or
+ * mi355_bn_resident_reset.  Synchronises.  Callers poll it where they synchronise anyway (train1.py: once per epoch;
+ * mi355.ops.bn_resident_check raises). */
 int mi355_bn_resident_timeouts(unsigned* out);
+/* Clears the give-up count and the arrival counters after a give-up has been handled.  Synchronises the device. */
+int mi355_bn_resident_reset(void);
+/* TEST HOOK: grid-barrier poll iterations before a block gives up (0 restores the default, 1 << 19 ~ 0.3 s).  Used by the
+ * tests to provoke a give-up and check that it is loud. */
+int mi355_bn_resident_set_spin_limit(unsigned limit);
 /* Run-time switch of the one-launch backward (1 on, 0 off, -1 back to the environment's choice); returns the previous value.
  * Switch it off while another kernel runs beside the backward on the same device (e.g. a collective overlapped with it): all
  * blocks of the one-launch form must be resident at once.  For the same reason two PROCESSES that share a GPU must not both use it
  * (train1.py / bench.py set MI355_BN_RESIDENT=0 when ranks share a device); a launch whose blocks could not all become resident
- * gives up after about 0.3 s and is counted by mi355_bn_resident_timeouts. */
+ * gives up after about 0.3 s, poisons its outputs with NaN and is counted by mi355_bn_resident_timeouts. */
 int mi355_bn_set_resident(int on);
 /* g <- (bit of relu_mask set) ? g : 0 in place; g [rows][C] bf16 / fp32, relu_mask as above.  The stand-alone form of what
  * mi355_conv_dgrad_masked_acc and mi355_bn_bwd (relu_mask) do on the fly: a residual block's last BatchNorm hands the

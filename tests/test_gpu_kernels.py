@@ -356,6 +356,50 @@ def test_bn_backward_one_launch_lds_resident(gpu, dt, shape, mode):
     assert ops.bn_resident_timeouts() == 0
 
 
+def test_bn_backward_one_launch_gives_up_loudly(gpu):
+    """A one-launch backward whose blocks cannot exchange their sums must not pass incomplete sums off as gradients: with the
+    spin bound shrunk to one poll (test hook) the early arrivers of a multi-block launch give up -> the launch is counted,
+    every gradient a failed block wrote is NaN, bn_resident_check raises, switches the one-launch form off and clears the
+    counters; after the reset (and the hook restored) the same call is exact again."""
+    import mi355
+    ops = _ops()
+    N, C, H, W = 64, 256, 32, 32                  # 4 channel groups x 64 row blocks: every block has plenty of work before it arrives
+    tdt = torch.bfloat16
+    g = torch.Generator(device='cpu').manual_seed(99)
+    to = lambda t: t.to(gpu).to(tdt).contiguous(memory_format=torch.channels_last)
+    xd, dyd = to(torch.randn(N, C, H, W, generator=g)), to(torch.randn(N, C, H, W, generator=g))
+    gamma, beta = torch.ones(C, device=gpu), torch.zeros(C, device=gpu)
+    rm, rv, nbt = torch.zeros(C, device=gpu), torch.ones(C, device=gpu), torch.zeros((), dtype=torch.int64, device=gpu)
+    y, mean, invstd = ops.bn_train_fwd(xd, None, gamma, beta, rm, rv, nbt, 1e-5, 0.1, False)
+
+    def bwd():
+        dg, db = torch.zeros(C, device=gpu), torch.zeros(C, device=gpu)
+        dx, _ = ops.bn_bwd(dyd, xd, None, gamma, mean, invstd, dg, db, False, False, False, beta=beta)
+        torch.cuda.synchronize()
+        return dx, dg, db
+    good = bwd()
+    assert ops.bn_resident_timeouts() == 0 and all(bool(torch.isfinite(t.float()).all()) for t in good)
+    prev = mi355.load().mi355_bn_set_resident(1)
+    try:
+        ops.bn_resident_set_spin_limit(1)
+        dx, dg, db = bwd()
+        n = ops.bn_resident_timeouts()
+        assert n > 0, 'the shrunk spin bound did not provoke a give-up'
+        assert bool(torch.isnan(dx.float()).any()), 'a block that gave up must poison its dx rows'
+        with pytest.raises(mi355.Mi355Error, match='give-up'):
+            ops.bn_resident_check('test')
+        assert ops.bn_resident_timeouts() == 0                       # cleared by the check
+        assert mi355.load().mi355_bn_set_resident(1) == 0            # ... which also switched the one-launch form off
+    finally:
+        ops.bn_resident_set_spin_limit(0)
+        ops.bn_resident_reset()
+        mi355.load().mi355_bn_set_resident(prev)
+    again = bwd()
+    assert ops.bn_resident_timeouts() == 0
+    for a, b in zip(again, good):
+        assert torch.equal(a, b)
+
+
 @pytest.mark.parametrize('dt', ['f32', 'bf16'])
 @pytest.mark.parametrize('shape', [(2, 64, 32, 32), (3, 64, 18, 14)])
 def test_stem_batchnorm_relu_maxpool_in_one_pass(gpu, dt, shape):
