@@ -1194,6 +1194,9 @@ static int dispatch_gather(GatherArgs& a, hipStream_t st) {
   (void)kchunks;
   // algorithmic bytes: every input element, weight and output element once
   ProfScope ps(st, flops, (double)a.a_bytes + (double)a.b_bytes * ntaps_tot / (a.ldb / a.Ci) + (double)Mtot * a.Nout * sizeof(T));
+  if constexpr (sizeof(T) == 2) {
+    if (pgemm_eligible(a, 2)) return dispatch_pgemm(a, st);       // 1x1 / unit stride: the persistent pipelined GEMM (pgemm.hip)
+  }
   static const int force = getenv("MI355_TILE") ? atoi(getenv("MI355_TILE")) : -1;   // experiment switch
   static const int dma_mode = getenv("MI355_DMA") ? atoi(getenv("MI355_DMA")) : 1;
   if (small) { launch_gather<T, 128, 64, true>(a, st); }

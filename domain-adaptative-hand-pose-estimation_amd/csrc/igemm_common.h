@@ -81,5 +81,9 @@ __device__ __forceinline__ uint4 buf_load16(__amdgpu_buffer_rsrc_t rs, int byte_
 }
 
 
+// Persistent pipelined GEMM for 1x1 / unit-stride convs (pgemm.hip): `a` filled exactly as for dispatch_gather.
+bool pgemm_eligible(const GatherArgs& a, int elem_size);
+int dispatch_pgemm(GatherArgs& a, hipStream_t st);
+
 // fp8-operand build of the gather GEMM (igemm_fp8.hip).  `a` is filled exactly as for the bf16 kernel (element = byte).
 int dispatch_gather_fp8(GatherArgs& a, hipStream_t st);

@@ -19,10 +19,11 @@ typedef __attribute__((ext_vector_type(2))) float f2;
 typedef __attribute__((ext_vector_type(8))) short bf16x8_t;
 typedef __attribute__((ext_vector_type(16))) float f32x16_t;
 
-enum { F_SRC1_SWAP = 0, F_SRC0_SWAP, F_DEFAULT, F_HI_BCAST, F_FMA_SRC0_SWAP, F_MUL_SRC0_SWAP, NFORMS };
+enum { F_SRC1_SWAP = 0, F_SRC0_SWAP, F_DEFAULT, F_HI_BCAST, F_FMA_SRC0_SWAP, F_MUL_SRC0_SWAP, F_SRC1_SWAP_INPLACE, F_SRC0_SWAP_INPLACE, NFORMS };
 static const char* form_name[NFORMS] = {"pk_add op_sel:[0,1] op_sel_hi:[1,0]", "pk_add op_sel:[1,0] op_sel_hi:[0,1]",
                                         "pk_add (default)", "pk_add op_sel_hi:[0,1]", "pk_fma op_sel:[1,0,0]",
-                                        "pk_mul op_sel:[1,0]"};
+                                        "pk_mul op_sel:[1,0]", "pk_add d=src0 op_sel:[0,1] op_sel_hi:[1,0]",
+                                        "pk_add d=src1 op_sel:[1,0] op_sel_hi:[0,1]"};
 enum { P_NONE = 0, P_MFMA, P_LDS, P_VMEM, NPARTNERS };
 static const char* partner_name[NPARTNERS] = {"alone", "beside MFMA waves", "beside LDS-read waves", "beside global-load waves"};
 
@@ -66,9 +67,19 @@ __device__ __forceinline__ void probe_body(const float* __restrict__ in, unsigne
       f2 c = {0.5f, 0.25f};
       asm volatile("v_pk_fma_f32 %0, %2, %3, %1 op_sel:[1,0,0]\n s_nop 1" : "=&v"(d) : "v"(a), "v"(b), "v"(c));
       e_lo = __builtin_fmaf(b1, 0.5f, a0); e_hi = __builtin_fmaf(b1, 0.25f, a1);
-    } else {
+    } else if constexpr (FORM == F_MUL_SRC0_SWAP) {
       asm volatile("v_pk_mul_f32 %0, %2, %1 op_sel:[1,0]\n s_nop 1" : "=&v"(d) : "v"(a), "v"(b));
       e_lo = b1 * a0; e_hi = b1 * a1;
+    } else if constexpr (FORM == F_SRC1_SWAP_INPLACE) {
+      // the form of the faulty epilogue: the destination IS src0 (accumulate in place), src1's halves swapped
+      d = a;
+      asm volatile("v_pk_add_f32 %0, %0, %1 op_sel:[0,1] op_sel_hi:[1,0]\n s_nop 1" : "+v"(d) : "v"(b));
+      e_lo = a0 + b1; e_hi = a1 + b0;
+    } else {
+      // the variant that cured the kernel (a3): the destination is src1, src0's halves swapped
+      d = a;
+      asm volatile("v_pk_add_f32 %0, %1, %0 op_sel:[1,0] op_sel_hi:[0,1]\n s_nop 1" : "+v"(d) : "v"(b));
+      e_lo = b1 + a0; e_hi = b0 + a1;
     }
     nlo += (d.x != e_lo) ? 1u : 0u;
     nhi += (d.y != e_hi) ? 1u : 0u;
@@ -149,5 +160,7 @@ int main() {
   run_form<F_HI_BCAST>(din, dsink, dbad, iters);
   run_form<F_FMA_SRC0_SWAP>(din, dsink, dbad, iters);
   run_form<F_MUL_SRC0_SWAP>(din, dsink, dbad, iters);
+  run_form<F_SRC1_SWAP_INPLACE>(din, dsink, dbad, iters);
+  run_form<F_SRC0_SWAP_INPLACE>(din, dsink, dbad, iters);
   return 0;
 }

@@ -36,6 +36,23 @@ def test_library_exports_every_header_symbol(lib_path):
     assert lib.mi355_version() >= 100
 
 
+def test_isa_gate_on_the_shipped_library(lib_path):
+    """build.py's gate: the linked library holds no packed-fp32 arithmetic whose op_sel takes a low result from a high
+    register (the instruction form behind the round-2 dropped-addend fault) -- and the gate itself
+    recognises such an instruction when it sees one."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('mi355_build', os.path.join(PKG, 'build.py'))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    assert mod.isa_gate(lib_path) > 100000                   # every device instruction of the library was inspected
+    bad = 'v_pk_add_f32 v[4:5], v[4:5], v[22:23] op_sel:[0,1] op_sel_hi:[1,0]'
+    ok = ['v_pk_add_f32 v[4:5], v[4:5], v[22:23]', 'v_pk_mul_f32 v[2:3], v[2:3], v[8:9] op_sel_hi:[0,1]',
+          'v_pk_mov_b32 v[22:23], v[22:23], v[22:23] op_sel:[1,0]']
+    hit = lambda ins: bool(mod._PK.search(ins) and mod._OPSEL.search(ins) and '1' in mod._OPSEL.search(ins).group(1))
+    assert hit(bad) and not any(hit(i) for i in ok)
+    assert '-fno-slp-vectorize' in mod.FLAGS
+
+
 def test_ctypes_table_matches_header(lib_path):
     import mi355
     assert sorted(mi355.SIGNATURES) == _header_symbols()
