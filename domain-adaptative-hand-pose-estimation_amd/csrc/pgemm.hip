@@ -1,27 +1,27 @@
-// Persistent, wave-specialised pipelined GEMM for the 1x1 / unit-stride convolutions (forward and input gradient), bf16, gfx950.
+// Persistent pipelined GEMM for the 1x1 / unit-stride convolutions (forward and input gradient), bf16, gfx950.
 //
 //   D[m][n] = epilogue( sum_k A[m][k] * B[n][k] )      A: [M][K] activations (NHWC rows ARE the GEMM rows: no gather),
-//                                                      B: [N][K] packed weights, K = channels (multiple of 64, >= 128)
+//                                                      B: [N][K] packed weights, K = channels (multiple of 64)
 //
-// Why a second kernel beside gather_gemm_kernel (igemm.hip).  A ResNet-50 iteration launches ~190 of these layers with
-// M = 4 K .. 16 K rows and K = 128 .. 2048: two to thirty-two 64-deep K steps per tile.  Measured on the general kernel and on a
-// first persistent build of this one (profiles/r03_pgemm_phases.txt: the same launch with its output stores, its MFMA step or its
-// LDS-DMA switched off): the phases of a tile -- operand fetch, MFMA, convert + stage + store (+ BatchNorm statistics) -- do not
-// overlap; each adds its full cost, and the instruction overhead of a tile alone (no loads, no MFMA, no stores) is 40 % of the
-// launch.  256 -> 1024 @16x16 (B=64): 21 us = skeleton 8.7 + LDS-DMA 3.9 + MFMA 5.3 + stores 3.9.  So the phases are made to
-// run CONCURRENTLY, inside one 512-thread block per CU:
-//   * waves 0-3 (one per SIMD) are the MFMA waves: they own the LDS ring (NS stages of [BM + BN] x 128-byte rows, filled by
-//     LDS-DMA with NS-1 K steps in flight, counted vmcnt, ONE barrier per K step, operand addresses = a per-lane offset fixed
-//     for the tile + k * 128 in the instruction's scalar offset) and the accumulators; when a tile's last K step is done they
-//     convert it ((acc + bias) * scale -> bf16) into one of two LDS staging tiles and go straight on to the next tile -- the ring
-//     never drains, the first K steps of the next tile are already in flight;
-//   * waves 4-7 (their SIMD partners) are the EPILOGUE waves: while the MFMA waves multiply tile i + 1 they stream tile i out of
-//     its staging tile -- residual / accumulate (+ bit mask) / ReLU, BatchNorm statistics of the output, coalesced 16-byte
-//     stores -- a share per K step, on the VALU, LDS-read and store paths the MFMA waves leave idle.  Their loads and stores
-//     have their own vmcnt, so the MFMA waves' counted waits stay exact.
-//   All eight waves meet at the one barrier per K step; the schedule is static (no flags, no polling):
-//       tile i staged before barrier (i+1)*nk | drained in steps (i+1)*nk .. (i+2)*nk-2 | statistics scratch in step (i+2)*nk-1
-//       | folded in step (i+2)*nk | its staging tile rewritten (tile i+2) at the end of step (i+3)*nk-1      [nk = K / 64 >= 2]
+// A second kernel beside gather_gemm_kernel (igemm.hip), OFF by default (MI355_PGEMM / mi355_set_pgemm).  Timed per layer in
+// isolation (graph replay, operands warm in L2 / Infinity Cache) it is 15 - 30 % faster on the K-heavy layers with M <= 16 K rows
+// and on narrow outputs, and slower where the BatchNorm-statistics epilogue dominates (profiles/r03_pgemm_phases.txt); inside the
+// training iteration and the inference forward, where operands arrive from HBM, it gains nothing: 33.31 vs 33.22 / 33.40 ms with
+// the selective policy (mode 1), 33.21 vs 32.65 ms and 20.5 k vs 21.5 k images/s when it takes every launch it fits (mode 2).  It
+// stays in the tree as the measured answer to "a persistent / weights-stationary kernel for the 1x1 convs", with its parity
+// tests (tests/test_gpu_kernels.py: identical bits to the gather kernel), not on the product path.  What it does:
+//   * the operands are plain row-major matrices, so a K step's global addresses are ONE per-lane offset per 1-KiB piece, fixed
+//     for the whole tile, plus a scalar (k * 128 bytes) in the instruction's soffset: no per-step vector arithmetic;
+//   * tiles travel global -> LDS by LDS-DMA (buffer_load ... lds) into a ring of NS stages with NS-1 K steps in flight (counted
+//     vmcnt), ONE barrier per K step (a raw s_barrier: the fences of __syncthreads() would drain the ring), no staging
+//     registers, no ds_write; a K step's fragment reads and MFMAs are one hand-scheduled asm statement;
+//   * the kernel is PERSISTENT: a block walks a list of tiles and the ring never drains -- the first K steps of the next tile are
+//     in flight while the current tile's epilogue streams out (staged in the ring slot its last K step has just freed);
+//   * same epilogue menu as the gather kernel: bias, device scalar (gradient-layer lambda), residual, accumulate (+ bit mask),
+//     ReLU (inference), BatchNorm statistics of the output (EPI = 1: kept for completeness and tests, not dispatched by default).
+// What was tried beyond this form and measured slower (wave-specialised MFMA / epilogue / loader roles on a static per-K-step
+// barrier schedule) is in profiles/r03_pgemm_phases.txt together with the in-kernel stamps that explain why: with 64 - 96 KB of
+// ring per CU the operand fill (~30 B/clk per CU, whichever waves issue it) bounds these layers, not the schedule.
 // Fragment layout, LDS row swizzle and MFMA operand order are those of gather_gemm_kernel (128-byte rows, chunk ^ (row >> 1) & 7,
 // D^T accumulators); both kernels produce the same bits for the same element.
 #include "common.h"
@@ -32,13 +32,11 @@
 template <int BM, int BN, int NS>
 struct PgSmem {
   static constexpr int kStage = (BM + BN) * 128;
-  static constexpr int kOut = BM * BN * 2;                   // one staging tile (bf16, swizzled, no padding)
-  static constexpr int kRing = NS * kStage;
-  static constexpr int kBytes = kRing + 2 * kOut;
-  static_assert(kBytes <= 160 * 1024, "ring + two staging tiles must fit the CU's LDS");
+  static constexpr int kBytes = NS * kStage;
+  static_assert(BM * BN * 2 <= kStage, "the epilogue stages the output tile in one ring slot");
 };
 
-// swizzled byte offset of 16-byte chunk c of output-tile row r in a staging tile (rows of BN * 2 bytes, no padding):
+// swizzled byte offset of 16-byte chunk c of output-tile row r in the epilogue staging image (rows of BN * 2 bytes, no padding):
 // 256-byte rows cover all 64 banks -> 16 rows need 16 chunk positions; 128-byte rows cover half -> row pairs alternate halves
 template <int BN> __device__ __forceinline__ int out_swz(int r, int c) {
   if constexpr (BN == 128) return r * 256 + ((c ^ (r & 15)) << 4);
@@ -62,187 +60,222 @@ __device__ __forceinline__ float lds_read4(unsigned a) { float v; asm volatile("
 // every LDS-DMA stage in flight.  All cross-wave traffic of this kernel is LDS traffic issued by the asm forms above and drained
 // by hand (lgkmcnt / counted vmcnt) before the barrier that publishes it; nothing is handed over through global memory.
 #define RAW_BARRIER() asm volatile("s_barrier" ::: "memory")
-// diagnostic builds of a launch (MI355_PG_DEBUG & 8): cycle stamps of block 0's wave 0 (MFMA role) and wave 4 (epilogue role)
-// go to a buffer of their own ([role][step][8] x 64-bit); nothing else reads them (guide section 7, in-kernel stamps)
-#define PG_STAMP(role, step, slot) do { if (stamp && (step) < 256) stamp[((role) * 256 + (step)) * 8 + (slot)] = __builtin_amdgcn_s_memtime(); } while (0)
 
 template <int BM, int BN, int NS, int EPI>
-__global__ __launch_bounds__(512) void pgemm_kernel(const GatherArgs p) {
-  constexpr int CH = 8;
+__global__ __launch_bounds__(256) void pgemm_kernel(const GatherArgs p) {
+  constexpr int CH = 8, NTHR = 256;
   constexpr int WM = BM / 2, WN = BN / 2, MT = WM / 32, NT = WN / 32;
-  constexpr int PA = BM / 32, PB = BN / 32;                  // 1-KiB LDS-DMA pieces per MFMA wave and stage
+  constexpr int PA = BM / 32, PB = BN / 32;                  // 1-KiB LDS-DMA pieces per wave and stage
   constexpr int DIST = NS - 1;                               // K steps in flight
   constexpr int CPR = BN / CH;                               // 16-byte chunks per output row
-  constexpr int IT = BM * CPR / 256;                         // chunks per epilogue thread and tile
-  static_assert(BM * CPR % 256 == 0, "whole passes only");
+  constexpr int IT = BM * CPR / NTHR;                        // chunks per thread and tile in the epilogue
+  constexpr int RSTEP = NTHR / CPR;                          // rows between a thread's consecutive chunks
+  static_assert(BM * CPR % NTHR == 0, "whole passes only");
   using SM = PgSmem<BM, BN, NS>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  const int wm0 = (wave >> 1) * WM, wn0 = (wave & 1) * WN;
   const unsigned smem_base = lds_addr(smem);
+  const int lc = t & 7, lr = t >> 3;
+  const int lcs = lc ^ ((lr >> 1) & 7);                      // the swizzle is applied on the SOURCE address
+  const int r31 = lane & 31, hi = lane >> 5;
   const int M = p.ph[0].M, K = p.Ci, nk = K >> 6, ntn = p.ntn;
-  const int dbg = p.hw;        // diagnostic launches only (MI355_PG_DEBUG): 1 no output stores, 2 no MFMA step, 4 no LDS-DMA
   const int G = (int)gridDim.x;
   const int pos = xcd_remap((int)blockIdx.x, G);             // blocks of one XCD take neighbouring tiles (same A rows)
   const int my_tiles = pos < p.ntiles ? (p.ntiles - pos + G - 1) / G : 0;
   const int total = my_tiles * nk;
   if (total == 0) return;
-  unsigned long long* stamp = ((dbg & 8) && blockIdx.x == 0 && (t == 0 || t == 256)) ? reinterpret_cast<unsigned long long*>(p.bnb_partial) : nullptr;
 
-  if (wave_u < 4) {
-    // ============================================================================================== MFMA waves
-    const int wm0 = (wave >> 1) * WM, wn0 = (wave & 1) * WN;
-    const int lc = t & 7, lr = t >> 3;
-    const int lcs = lc ^ ((lr >> 1) & 7);                    // the swizzle is applied on the SOURCE address
-    const int r31 = lane & 31, hi = lane >> 5;
-    const __amdgpu_buffer_rsrc_t rsA = make_rsrc(p.A, p.a_bytes), rsB = make_rsrc(p.B, p.b_bytes);
+  const __amdgpu_buffer_rsrc_t rsA = make_rsrc(p.A, p.a_bytes), rsB = make_rsrc(p.B, p.b_bytes);
 
-    // ---- issue side: tile / K step of the next LDS-DMA stage to launch
-    int is_tile = 0, is_kt = 0, is_gs = 0;
-    int voffA[PA], voffB[PB];
-    auto set_issue_tile = [&](int i) {
-      const int lin = i * G + pos, tm = lin / ntn, tn = lin - tm * ntn;
+  // ---- issue side: tile / K step of the next LDS-DMA stage to launch
+  int is_tile = 0, is_kt = 0, is_gs = 0;
+  int voffA[PA], voffB[PB];
+  auto set_issue_tile = [&](int i) {
+    const int lin = i * G + pos, tm = lin / ntn, tn = lin - tm * ntn;
 #pragma unroll
-      for (int j = 0; j < PA; ++j) { const int m = tm * BM + j * 32 + lr; voffA[j] = m < M ? (m * K + lcs * CH) * 2 : OOB_OFF; }
+    for (int j = 0; j < PA; ++j) { const int m = tm * BM + j * 32 + lr; voffA[j] = m < M ? (m * K + lcs * CH) * 2 : OOB_OFF; }
 #pragma unroll
-      for (int j = 0; j < PB; ++j) { const int n = tn * BN + j * 32 + lr; voffB[j] = n < p.Nout ? (n * p.ldb + lcs * CH) * 2 : OOB_OFF; }
-    };
-    auto issue = [&]() {                                     // stage is_gs -> ring slot is_gs % NS
-      const int slot = is_gs % NS;
-      const int soff = is_kt * 128;
-      (void)slot; (void)soff;
+    for (int j = 0; j < PB; ++j) { const int n = tn * BN + j * 32 + lr; voffB[j] = n < p.Nout ? (n * p.ldb + lcs * CH) * 2 : OOB_OFF; }
+  };
+  auto issue = [&]() {                                       // stage is_gs -> ring slot is_gs % NS
+    const int slot = is_gs % NS;
+    const int soff = is_kt * 128;
+    (void)slot; (void)soff; (void)wave_u;
 #if defined(__HIP_DEVICE_COMPILE__)
-      if (!(dbg & 4)) {
-        typedef __attribute__((address_space(3))) void* ldsp;
-        char* sa = smem + slot * SM::kStage + wave_u * 1024;
-        char* sb = sa + BM * 128;
+    typedef __attribute__((address_space(3))) void* ldsp;
+    char* sa = smem + slot * SM::kStage + wave_u * 1024;
+    char* sb = sa + BM * 128;
 #pragma unroll
-        for (int j = 0; j < PA; ++j) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (ldsp)(sa + j * 4096), 16, voffA[j], soff, 0, 0);
+    for (int j = 0; j < PA; ++j) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (ldsp)(sa + j * 4096), 16, voffA[j], soff, 0, 0);
 #pragma unroll
-        for (int j = 0; j < PB; ++j) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (ldsp)(sb + j * 4096), 16, voffB[j], soff, 0, 0);
-      }
+    for (int j = 0; j < PB; ++j) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (ldsp)(sb + j * 4096), 16, voffB[j], soff, 0, 0);
 #endif
-      ++is_gs;
-      if (++is_kt == nk) { is_kt = 0; ++is_tile; if (is_tile < my_tiles) set_issue_tile(is_tile); }
-    };
+    ++is_gs;
+    if (++is_kt == nk) { is_kt = 0; ++is_tile; if (is_tile < my_tiles) set_issue_tile(is_tile); }
+  };
 
-    f32x16_t acc[MT][NT];
-    auto zero_acc = [&]() {
+  f32x16_t acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;       // (defined values for the first asm statement; every tile's first MFMAs take C = 0)
+  // fragment byte offsets inside a stage (fixed per lane): row part + the swizzled chunk of every 16-deep sub-step
+  unsigned fa[MT][4], fb[NT][4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+#pragma unroll
+    for (int i = 0; i < MT; ++i) fa[i][s] = (unsigned)swz128(wm0 + i * 32 + r31, 2 * s + hi);
+#pragma unroll
+    for (int j = 0; j < NT; ++j) fb[j][s] = (unsigned)(BM * 128 + swz128(wn0 + j * 32 + r31, 2 * s + hi));
+  }
+  // One K step = ONE asm statement: 4 x (MT + NT) fragment reads, software-pipelined one 16-deep sub-step ahead of the 4 x MT x NT
+  // MFMAs (two fragment buffers), waits counted in lgkmcnt.  hipcc would sink the MFMAs below the later waits and shuttle the
+  // accumulators between the two register files around the conditional epilogue; here they stay in the accumulator file.
+#define PG_MFMA(ACC, B, A) "v_mfma_f32_32x32x16_bf16 " ACC ", " B ", " A ", " ACC "\n"
+#define PG_MFMAZ(ACC, B, A) "v_mfma_f32_32x32x16_bf16 " ACC ", " B ", " A ", 0\n"
+#define PG_RD(DST, ADDR) "ds_read_b128 " DST ", " ADDR "\n"
+  auto compute = [&](unsigned stage_addr, int first) {      // first: the tile's first K step (its first MFMAs take C = 0)
+    unsigned xa[MT][4], xb[NT][4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+#pragma unroll
+      for (int i = 0; i < MT; ++i) xa[i][s] = stage_addr + fa[i][s];
+#pragma unroll
+      for (int j = 0; j < NT; ++j) xb[j][s] = stage_addr + fb[j][s];
+    }
+    if constexpr (MT == 2 && NT == 2) {
+      bf16x8_t a0, a1, b0, b1, c0, c1, d0, d1;      // buffer 0: a0 a1 (A rows) b0 b1 (B rows); buffer 1: c0 c1 / d0 d1
+      asm volatile(
+          PG_RD("%4", "%12") PG_RD("%6", "%20") PG_RD("%5", "%16") PG_RD("%7", "%24")
+          PG_RD("%8", "%13") PG_RD("%10", "%21") PG_RD("%9", "%17") PG_RD("%11", "%25")
+          "s_waitcnt lgkmcnt(4)\n"
+          "s_cmp_lg_u32 %28, 0\n\ts_cbranch_scc1 1f\n"
+          PG_MFMA("%0", "%6", "%4") PG_MFMA("%1", "%7", "%4") PG_MFMA("%2", "%6", "%5") PG_MFMA("%3", "%7", "%5")
+          "s_branch 2f\n1:\n"
+          PG_MFMAZ("%0", "%6", "%4") PG_MFMAZ("%1", "%7", "%4") PG_MFMAZ("%2", "%6", "%5") PG_MFMAZ("%3", "%7", "%5")
+          "2:\n"
+          PG_RD("%4", "%14") PG_RD("%6", "%22") PG_RD("%5", "%18") PG_RD("%7", "%26")
+          "s_waitcnt lgkmcnt(4)\n"
+          PG_MFMA("%0", "%10", "%8") PG_MFMA("%1", "%11", "%8") PG_MFMA("%2", "%10", "%9") PG_MFMA("%3", "%11", "%9")
+          PG_RD("%8", "%15") PG_RD("%10", "%23") PG_RD("%9", "%19") PG_RD("%11", "%27")
+          "s_waitcnt lgkmcnt(4)\n"
+          PG_MFMA("%0", "%6", "%4") PG_MFMA("%1", "%7", "%4") PG_MFMA("%2", "%6", "%5") PG_MFMA("%3", "%7", "%5")
+          "s_waitcnt lgkmcnt(0)\n"
+          PG_MFMA("%0", "%10", "%8") PG_MFMA("%1", "%11", "%8") PG_MFMA("%2", "%10", "%9") PG_MFMA("%3", "%11", "%9")
+          : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[1][0]), "+v"(acc[1][1]),
+            "=&v"(a0), "=&v"(a1), "=&v"(b0), "=&v"(b1), "=&v"(c0), "=&v"(c1), "=&v"(d0), "=&v"(d1)
+          : "v"(xa[0][0]), "v"(xa[0][1]), "v"(xa[0][2]), "v"(xa[0][3]), "v"(xa[1][0]), "v"(xa[1][1]), "v"(xa[1][2]), "v"(xa[1][3]),
+            "v"(xb[0][0]), "v"(xb[0][1]), "v"(xb[0][2]), "v"(xb[0][3]), "v"(xb[1][0]), "v"(xb[1][1]), "v"(xb[1][2]), "v"(xb[1][3]), "s"(first)
+          : "memory", "scc");
+    } else if constexpr (MT == 1 && NT == 2) {
+      bf16x8_t a0, b0, b1, c0, d0, d1;
+      asm volatile(
+          PG_RD("%2", "%8") PG_RD("%3", "%12") PG_RD("%4", "%16")
+          PG_RD("%5", "%9") PG_RD("%6", "%13") PG_RD("%7", "%17")
+          "s_waitcnt lgkmcnt(3)\n"
+          "s_cmp_lg_u32 %20, 0\n\ts_cbranch_scc1 1f\n"
+          PG_MFMA("%0", "%3", "%2") PG_MFMA("%1", "%4", "%2")
+          "s_branch 2f\n1:\n"
+          PG_MFMAZ("%0", "%3", "%2") PG_MFMAZ("%1", "%4", "%2")
+          "2:\n"
+          PG_RD("%2", "%10") PG_RD("%3", "%14") PG_RD("%4", "%18")
+          "s_waitcnt lgkmcnt(3)\n"
+          PG_MFMA("%0", "%6", "%5") PG_MFMA("%1", "%7", "%5")
+          PG_RD("%5", "%11") PG_RD("%6", "%15") PG_RD("%7", "%19")
+          "s_waitcnt lgkmcnt(3)\n"
+          PG_MFMA("%0", "%3", "%2") PG_MFMA("%1", "%4", "%2")
+          "s_waitcnt lgkmcnt(0)\n"
+          PG_MFMA("%0", "%6", "%5") PG_MFMA("%1", "%7", "%5")
+          : "+v"(acc[0][0]), "+v"(acc[0][1]), "=&v"(a0), "=&v"(b0), "=&v"(b1), "=&v"(c0), "=&v"(d0), "=&v"(d1)
+          : "v"(xa[0][0]), "v"(xa[0][1]), "v"(xa[0][2]), "v"(xa[0][3]),
+            "v"(xb[0][0]), "v"(xb[0][1]), "v"(xb[0][2]), "v"(xb[0][3]), "v"(xb[1][0]), "v"(xb[1][1]), "v"(xb[1][2]), "v"(xb[1][3]), "s"(first)
+          : "memory", "scc");
+    } else if constexpr (MT == 2 && NT == 1) {
+      bf16x8_t a0, a1, b0, c0, c1, d0;
+      asm volatile(
+          PG_RD("%2", "%8") PG_RD("%3", "%12") PG_RD("%4", "%16")
+          PG_RD("%5", "%9") PG_RD("%6", "%13") PG_RD("%7", "%17")
+          "s_waitcnt lgkmcnt(3)\n"
+          "s_cmp_lg_u32 %20, 0\n\ts_cbranch_scc1 1f\n"
+          PG_MFMA("%0", "%4", "%2") PG_MFMA("%1", "%4", "%3")
+          "s_branch 2f\n1:\n"
+          PG_MFMAZ("%0", "%4", "%2") PG_MFMAZ("%1", "%4", "%3")
+          "2:\n"
+          PG_RD("%2", "%10") PG_RD("%3", "%14") PG_RD("%4", "%18")
+          "s_waitcnt lgkmcnt(3)\n"
+          PG_MFMA("%0", "%7", "%5") PG_MFMA("%1", "%7", "%6")
+          PG_RD("%5", "%11") PG_RD("%6", "%15") PG_RD("%7", "%19")
+          "s_waitcnt lgkmcnt(3)\n"
+          PG_MFMA("%0", "%4", "%2") PG_MFMA("%1", "%4", "%3")
+          "s_waitcnt lgkmcnt(0)\n"
+          PG_MFMA("%0", "%7", "%5") PG_MFMA("%1", "%7", "%6")
+          : "+v"(acc[0][0]), "+v"(acc[1][0]), "=&v"(a0), "=&v"(a1), "=&v"(b0), "=&v"(c0), "=&v"(c1), "=&v"(d0)
+          : "v"(xa[0][0]), "v"(xa[0][1]), "v"(xa[0][2]), "v"(xa[0][3]), "v"(xa[1][0]), "v"(xa[1][1]), "v"(xa[1][2]), "v"(xa[1][3]),
+            "v"(xb[0][0]), "v"(xb[0][1]), "v"(xb[0][2]), "v"(xb[0][3]), "s"(first)
+          : "memory", "scc");
+    } else {
+      bf16x8_t a0, b0, c0, d0;
+      asm volatile(
+          PG_RD("%1", "%5") PG_RD("%2", "%9") PG_RD("%3", "%6") PG_RD("%4", "%10")
+          "s_waitcnt lgkmcnt(2)\n"
+          "s_cmp_lg_u32 %13, 0\n\ts_cbranch_scc1 1f\n"
+          PG_MFMA("%0", "%2", "%1")
+          "s_branch 2f\n1:\n"
+          PG_MFMAZ("%0", "%2", "%1")
+          "2:\n"
+          PG_RD("%1", "%7") PG_RD("%2", "%11")
+          "s_waitcnt lgkmcnt(2)\n"
+          PG_MFMA("%0", "%4", "%3")
+          PG_RD("%3", "%8") PG_RD("%4", "%12")
+          "s_waitcnt lgkmcnt(2)\n"
+          PG_MFMA("%0", "%2", "%1")
+          "s_waitcnt lgkmcnt(0)\n"
+          PG_MFMA("%0", "%4", "%3")
+          : "+v"(acc[0][0]), "=&v"(a0), "=&v"(b0), "=&v"(c0), "=&v"(d0)
+          : "v"(xa[0][0]), "v"(xa[0][1]), "v"(xa[0][2]), "v"(xa[0][3]), "v"(xb[0][0]), "v"(xb[0][1]), "v"(xb[0][2]), "v"(xb[0][3]), "s"(first)
+          : "memory", "scc");
+    }
+  };
+#undef PG_MFMA
+#undef PG_MFMAZ
+
+  // ---- epilogue of tile (tm, tn): (acc + bias) * scale -> bf16 -> ring slot `outs` -> coalesced 16-byte rows (+ the extras)
+  // staging offsets of this lane's 4-wide column runs (row part for i = 0; 32 rows further down the swizzle pattern repeats)
+  unsigned so[NT][4];
+#pragma unroll
+  for (int j = 0; j < NT; ++j)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) { const int nl = wn0 + j * 32 + 8 * g + 4 * hi; so[j][g] = (unsigned)(out_swz<BN>(wm0 + r31, nl >> 3) + (nl & 7) * 2); }
+  const float scale = p.scale ? *p.scale : 1.0f;
+  const bool affine = p.bias != nullptr || p.scale != nullptr;
+  bf16_t* __restrict__ D = reinterpret_cast<bf16_t*>(p.D);
+  const bf16_t* __restrict__ R = reinterpret_cast<const bf16_t*>(p.residual);
+  const bool plain = !R && !p.accumulate && !p.relu;         // the staged words go out as they are
+  const int ec = t % CPR, er0 = t / CPR;                     // this thread's chunk column (fixed: 256 % CPR == 0) and first row
+  const unsigned rd0 = (unsigned)out_swz<BN>(er0, ec);       // chunk k of the thread sits RSTEP rows below chunk k - 1: a constant distance
+  auto epilogue = [&](unsigned outs, int tm, int tn) {
+    const int m0 = tm * BM, n0 = tn * BN;
+    asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");       // the last MFMAs' results before hipcc's reads of them (asm is opaque to its hazard pass)
+    RAW_BARRIER();                                           // every wave has finished reading this slot (last K step)
+    if (!affine) {
 #pragma unroll
       for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int j = 0; j < NT; ++j)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    };
-    // fragment byte offsets inside a stage (fixed per lane): row part + the swizzled chunk of every 16-deep sub-step
-    unsigned fa[MT][4], fb[NT][4];
+          for (int g = 0; g < 4; ++g) {
+            union { bf16_t h[4]; uint2 q; } u;
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-#pragma unroll
-      for (int i = 0; i < MT; ++i) fa[i][s] = (unsigned)swz128(wm0 + i * 32 + r31, 2 * s + hi);
-#pragma unroll
-      for (int j = 0; j < NT; ++j) fb[j][s] = (unsigned)(BM * 128 + swz128(wn0 + j * 32 + r31, 2 * s + hi));
-    }
-    // One K step = ONE asm statement: 4 x (MT + NT) fragment reads, software-pipelined one 16-deep sub-step ahead of the 4 x MT x NT
-    // MFMAs (two fragment buffers), waits counted in lgkmcnt.  hipcc would sink the MFMAs below the later waits and shuttle the
-    // accumulators between the two register files around the conditional epilogue; here they stay in the accumulator file.
-#define PG_MFMA(ACC, B, A) "v_mfma_f32_32x32x16_bf16 " ACC ", " B ", " A ", " ACC "\n"
-#define PG_RD(DST, ADDR) "ds_read_b128 " DST ", " ADDR "\n"
-    auto compute = [&](unsigned stage_addr) {
-      unsigned xa[MT][4], xb[NT][4];
-#pragma unroll
-      for (int s = 0; s < 4; ++s) {
-#pragma unroll
-        for (int i = 0; i < MT; ++i) xa[i][s] = stage_addr + fa[i][s];
-#pragma unroll
-        for (int j = 0; j < NT; ++j) xb[j][s] = stage_addr + fb[j][s];
-      }
-      if constexpr (MT == 2 && NT == 2) {
-        bf16x8_t a0, a1, b0, b1, c0, c1, d0, d1;      // buffer 0: a0 a1 (A rows) b0 b1 (B rows); buffer 1: c0 c1 / d0 d1
-        asm volatile(
-            PG_RD("%4", "%12") PG_RD("%6", "%20") PG_RD("%5", "%16") PG_RD("%7", "%24")
-            PG_RD("%8", "%13") PG_RD("%10", "%21") PG_RD("%9", "%17") PG_RD("%11", "%25")
-            "s_waitcnt lgkmcnt(4)\n"
-            PG_MFMA("%0", "%6", "%4") PG_MFMA("%1", "%7", "%4") PG_MFMA("%2", "%6", "%5") PG_MFMA("%3", "%7", "%5")
-            PG_RD("%4", "%14") PG_RD("%6", "%22") PG_RD("%5", "%18") PG_RD("%7", "%26")
-            "s_waitcnt lgkmcnt(4)\n"
-            PG_MFMA("%0", "%10", "%8") PG_MFMA("%1", "%11", "%8") PG_MFMA("%2", "%10", "%9") PG_MFMA("%3", "%11", "%9")
-            PG_RD("%8", "%15") PG_RD("%10", "%23") PG_RD("%9", "%19") PG_RD("%11", "%27")
-            "s_waitcnt lgkmcnt(4)\n"
-            PG_MFMA("%0", "%6", "%4") PG_MFMA("%1", "%7", "%4") PG_MFMA("%2", "%6", "%5") PG_MFMA("%3", "%7", "%5")
-            "s_waitcnt lgkmcnt(0)\n"
-            PG_MFMA("%0", "%10", "%8") PG_MFMA("%1", "%11", "%8") PG_MFMA("%2", "%10", "%9") PG_MFMA("%3", "%11", "%9")
-            : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[1][0]), "+v"(acc[1][1]),
-              "=&v"(a0), "=&v"(a1), "=&v"(b0), "=&v"(b1), "=&v"(c0), "=&v"(c1), "=&v"(d0), "=&v"(d1)
-            : "v"(xa[0][0]), "v"(xa[0][1]), "v"(xa[0][2]), "v"(xa[0][3]), "v"(xa[1][0]), "v"(xa[1][1]), "v"(xa[1][2]), "v"(xa[1][3]),
-              "v"(xb[0][0]), "v"(xb[0][1]), "v"(xb[0][2]), "v"(xb[0][3]), "v"(xb[1][0]), "v"(xb[1][1]), "v"(xb[1][2]), "v"(xb[1][3])
-            : "memory");
-      } else if constexpr (MT == 1 && NT == 2) {
-        bf16x8_t a0, b0, b1, c0, d0, d1;
-        asm volatile(
-            PG_RD("%2", "%8") PG_RD("%3", "%12") PG_RD("%4", "%16")
-            PG_RD("%5", "%9") PG_RD("%6", "%13") PG_RD("%7", "%17")
-            "s_waitcnt lgkmcnt(3)\n"
-            PG_MFMA("%0", "%3", "%2") PG_MFMA("%1", "%4", "%2")
-            PG_RD("%2", "%10") PG_RD("%3", "%14") PG_RD("%4", "%18")
-            "s_waitcnt lgkmcnt(3)\n"
-            PG_MFMA("%0", "%6", "%5") PG_MFMA("%1", "%7", "%5")
-            PG_RD("%5", "%11") PG_RD("%6", "%15") PG_RD("%7", "%19")
-            "s_waitcnt lgkmcnt(3)\n"
-            PG_MFMA("%0", "%3", "%2") PG_MFMA("%1", "%4", "%2")
-            "s_waitcnt lgkmcnt(0)\n"
-            PG_MFMA("%0", "%6", "%5") PG_MFMA("%1", "%7", "%5")
-            : "+v"(acc[0][0]), "+v"(acc[0][1]), "=&v"(a0), "=&v"(b0), "=&v"(b1), "=&v"(c0), "=&v"(d0), "=&v"(d1)
-            : "v"(xa[0][0]), "v"(xa[0][1]), "v"(xa[0][2]), "v"(xa[0][3]),
-              "v"(xb[0][0]), "v"(xb[0][1]), "v"(xb[0][2]), "v"(xb[0][3]), "v"(xb[1][0]), "v"(xb[1][1]), "v"(xb[1][2]), "v"(xb[1][3])
-            : "memory");
-      } else if constexpr (MT == 2 && NT == 1) {
-        bf16x8_t a0, a1, b0, c0, c1, d0;
-        asm volatile(
-            PG_RD("%2", "%8") PG_RD("%3", "%12") PG_RD("%4", "%16")
-            PG_RD("%5", "%9") PG_RD("%6", "%13") PG_RD("%7", "%17")
-            "s_waitcnt lgkmcnt(3)\n"
-            PG_MFMA("%0", "%4", "%2") PG_MFMA("%1", "%4", "%3")
-            PG_RD("%2", "%10") PG_RD("%3", "%14") PG_RD("%4", "%18")
-            "s_waitcnt lgkmcnt(3)\n"
-            PG_MFMA("%0", "%7", "%5") PG_MFMA("%1", "%7", "%6")
-            PG_RD("%5", "%11") PG_RD("%6", "%15") PG_RD("%7", "%19")
-            "s_waitcnt lgkmcnt(3)\n"
-            PG_MFMA("%0", "%4", "%2") PG_MFMA("%1", "%4", "%3")
-            "s_waitcnt lgkmcnt(0)\n"
-            PG_MFMA("%0", "%7", "%5") PG_MFMA("%1", "%7", "%6")
-            : "+v"(acc[0][0]), "+v"(acc[1][0]), "=&v"(a0), "=&v"(a1), "=&v"(b0), "=&v"(c0), "=&v"(c1), "=&v"(d0)
-            : "v"(xa[0][0]), "v"(xa[0][1]), "v"(xa[0][2]), "v"(xa[0][3]), "v"(xa[1][0]), "v"(xa[1][1]), "v"(xa[1][2]), "v"(xa[1][3]),
-              "v"(xb[0][0]), "v"(xb[0][1]), "v"(xb[0][2]), "v"(xb[0][3])
-            : "memory");
-      } else {
-        bf16x8_t a0, b0, c0, d0;
-        asm volatile(
-            PG_RD("%1", "%5") PG_RD("%2", "%9") PG_RD("%3", "%6") PG_RD("%4", "%10")
-            "s_waitcnt lgkmcnt(2)\n"
-            PG_MFMA("%0", "%2", "%1")
-            PG_RD("%1", "%7") PG_RD("%2", "%11")
-            "s_waitcnt lgkmcnt(2)\n"
-            PG_MFMA("%0", "%4", "%3")
-            PG_RD("%3", "%8") PG_RD("%4", "%12")
-            "s_waitcnt lgkmcnt(2)\n"
-            PG_MFMA("%0", "%2", "%1")
-            "s_waitcnt lgkmcnt(0)\n"
-            PG_MFMA("%0", "%4", "%3")
-            : "+v"(acc[0][0]), "=&v"(a0), "=&v"(b0), "=&v"(c0), "=&v"(d0)
-            : "v"(xa[0][0]), "v"(xa[0][1]), "v"(xa[0][2]), "v"(xa[0][3]), "v"(xb[0][0]), "v"(xb[0][1]), "v"(xb[0][2]), "v"(xb[0][3])
-            : "memory");
-      }
-    };
-#undef PG_MFMA
-#undef PG_RD
-
-    // ---- hand-over of a finished tile: (acc + bias) * scale -> bf16 -> staging tile `outs`
-    const float scale = p.scale ? *p.scale : 1.0f;
-    auto stage_out = [&](unsigned outs, int n0) {
-      float4 bq[NT][4];                                      // bias of this lane's 4-wide column runs, fetched up front
+            for (int e = 0; e < 4; ++e) u.h[e] = (bf16_t)acc[i][j][4 * g + e];
+            lds_write8(outs + so[j][g] + (unsigned)(i * 32 * BN * 2), u.q);
+          }
+    } else {
+      float4 bq[NT][4];                                      // bias of this lane's column runs, fetched up front
 #pragma unroll
       for (int j = 0; j < NT; ++j)
 #pragma unroll
@@ -250,101 +283,46 @@ __global__ __launch_bounds__(512) void pgemm_kernel(const GatherArgs p) {
           const int n = n0 + wn0 + j * 32 + 8 * g + 4 * hi;  // Nout is a multiple of 8: a run is inside or outside as a whole
           bq[j][g] = (p.bias && n < p.Nout) ? *reinterpret_cast<const float4*>(p.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
-      asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");     // the last MFMAs' results before hipcc's reads of them (asm is opaque to its hazard pass)
 #pragma unroll
       for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int j = 0; j < NT; ++j)
 #pragma unroll
           for (int g = 0; g < 4; ++g) {
-            const int ml = wm0 + i * 32 + r31, nl = wn0 + j * 32 + 8 * g + 4 * hi;
             const float bb[4] = {bq[j][g].x, bq[j][g].y, bq[j][g].z, bq[j][g].w};
             union { bf16_t h[4]; uint2 q; } u;
 #pragma unroll
             for (int e = 0; e < 4; ++e) u.h[e] = (bf16_t)((acc[i][j][4 * g + e] + bb[e]) * scale);
-            lds_write8(outs + out_swz<BN>(ml, nl >> 3) + (nl & 7) * 2, u.q);
+            lds_write8(outs + so[j][g] + (unsigned)(i * 32 * BN * 2), u.q);
           }
-      LDS_WAIT_ALL();                                        // ... published by the next barrier
-    };
-
-    // ---- the pipeline
-    set_issue_tile(0);
-#pragma unroll
-    for (int d = 0; d < DIST; ++d)
-      if (is_gs < total) issue();
-    int kt = 0, tile_i = 0;
-    zero_acc();
-    for (int gs = 0; gs < total; ++gs) {
-      PG_STAMP(0, gs, 0);
-      // this wave's pieces of stage gs have landed once at most the pieces of the DIST-1 younger stages are outstanding
-      // (the MFMA waves issue nothing else that counts in vmcnt except the bias loads of stage_out, which hipcc waits for itself)
-#if defined(__HIP_DEVICE_COMPILE__)
-      if (gs + DIST - 1 < total && DIST > 1) {
-        if constexpr ((DIST - 1) * (PA + PB) == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else if constexpr ((DIST - 1) * (PA + PB) == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        else if constexpr ((DIST - 1) * (PA + PB) == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else if constexpr ((DIST - 1) * (PA + PB) == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-        else if constexpr ((DIST - 1) * (PA + PB) == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      } else {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      }
-#endif
-      PG_STAMP(0, gs, 1);
-      RAW_BARRIER();                                         // barrier gs: everyone's pieces of stage gs have landed, slot (gs - 1) % NS is free
-      PG_STAMP(0, gs, 2);
-      if (is_gs < total) issue();                            // stage gs + DIST -> the slot stage gs - 1 has just left
-      const unsigned as = smem_base + (unsigned)((gs % NS) * SM::kStage);
-      PG_STAMP(0, gs, 3);
-      __builtin_amdgcn_s_setprio(1);
-      if (!(dbg & 2)) compute(as);
-      __builtin_amdgcn_s_setprio(0);
-      PG_STAMP(0, gs, 4);
-      if (++kt == nk) {
-        const int lin = tile_i * G + pos, tm = lin / ntn, tn = lin - tm * ntn;
-        stage_out(smem_base + (unsigned)(SM::kRing + (tile_i & 1) * SM::kOut), tn * BN);
-        zero_acc();
-        kt = 0; ++tile_i;
-      }
-      PG_STAMP(0, gs, 5);
     }
-    RAW_BARRIER();                                           // barrier `total`: the last tile is staged
-    return;
-  }
-
-  // ================================================================================================ epilogue waves
-  const int et = t - 256;
-  bf16_t* __restrict__ D = reinterpret_cast<bf16_t*>(p.D);
-  const bf16_t* __restrict__ R = reinterpret_cast<const bf16_t*>(p.residual);
-  constexpr bool stats = EPI == 1;
-  const bool plain = !R && !p.accumulate && !p.relu;         // the staged words go out as they are
-  const int Q = (IT + nk - 2) / (nk - 1);                    // chunks per thread and K step: a tile is drained in nk - 1 steps
-  const int ec = et % CPR, er0 = et / CPR;                   // this thread's chunk column (fixed: 256 % CPR == 0) and first row
-  float sn = 0.f, smean[CH], sm2[CH];
+    LDS_WAIT_ALL();
+    RAW_BARRIER();
+    constexpr bool stats = EPI == 1;
+    float sn = 0.f, smean[CH], sm2[CH];
 #pragma unroll
-  for (int e = 0; e < CH; ++e) { smean[e] = 0.f; sm2[e] = 0.f; }
-
-  auto tile_coords = [&](int i, int& tm, int& tn) { const int lin = i * G + pos; tm = lin / ntn; tn = lin - tm * ntn; };
-  // chunks [k0, k1) of this thread for tile i
-  auto drain = [&](int i, int k0, int k1) {
-    int tm, tn; tile_coords(i, tm, tn);
-    const char* outs = smem + SM::kRing + (i & 1) * SM::kOut;
-    const int n = tn * BN + ec * CH;
-    for (int k = k0; k < k1; ++k) {
-      const int r = er0 + k * (256 / CPR);
-      const int m = tm * BM + r;
-      if (m >= M || n >= p.Nout) continue;
-      const uint4 q = *reinterpret_cast<const uint4*>(outs + out_swz<BN>(r, ec));
-      const size_t g = (size_t)m * p.ldd + n;
-      float v[CH];
-      if (stats || !plain) Chunk<bf16_t>::unpack(q, v);
+    for (int e = 0; e < CH; ++e) { smean[e] = 0.f; sm2[e] = 0.f; }
+    const int n = n0 + ec * CH;
+    const int rows_left = M - (m0 + er0);                    // chunk k is inside the matrix iff k * RSTEP < rows_left
+    const size_t g0 = (size_t)(m0 + er0) * p.ldd + n;
+    u32x4_t q[IT];
+#pragma unroll
+    for (int k = 0; k < IT; ++k) q[k] = lds_read16u(outs + rd0 + (unsigned)(k * RSTEP * BN * 2));
+#pragma unroll
+    for (int k = 0; k < IT; ++k) {
+      // the k-th staged chunk has arrived once only the IT - 1 - k younger reads are outstanding
+      asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(q[k]) : "n"(IT - 1 - k));
+      if (k * RSTEP >= rows_left || n >= p.Nout) continue;
+      const size_t g = g0 + (size_t)k * RSTEP * p.ldd;
+      const uint4 qk = make_uint4(q[k][0], q[k][1], q[k][2], q[k][3]);
+      if (!stats && plain) { *reinterpret_cast<uint4*>(D + g) = qk; continue; }
+      float v[CH]; Chunk<bf16_t>::unpack(qk, v);
       if (stats) {
         sn += 1.f; const float inv = 1.f / sn;
 #pragma unroll
         for (int e = 0; e < CH; ++e) { const float d = v[e] - smean[e]; smean[e] += d * inv; sm2[e] += d * (v[e] - smean[e]); }
+        if (plain) { *reinterpret_cast<uint4*>(D + g) = qk; continue; }
       }
-      if (dbg & 1) continue;
-      if (plain) { *reinterpret_cast<uint4*>(D + g) = q; continue; }
       if (R) { float w[CH]; Chunk<bf16_t>::load(R + g, w);
 #pragma unroll
         for (int e = 0; e < CH; ++e) v[e] += w[e]; }
@@ -359,11 +337,8 @@ __global__ __launch_bounds__(512) void pgemm_kernel(const GatherArgs p) {
         for (int e = 0; e < CH; ++e) v[e] = v[e] < 0.f ? 0.f : v[e]; }
       Chunk<bf16_t>::store(D + g, v);
     }
-  };
-  // statistics of tile i: fold this thread's rows with the other row lanes of its wave, leave the wave's record in the tile's
-  // own staging tile (every wave has finished reading it: the barrier in front of this step), restart the running sums
-  auto stats_scratch = [&](int i) {
     if constexpr (stats) {
+      constexpr int NW = NTHR / 64;
 #pragma unroll
       for (int o = CPR; o < 64; o <<= 1) {
         const float nb = __shfl_down(sn, o, 64);
@@ -376,52 +351,71 @@ __global__ __launch_bounds__(512) void pgemm_kernel(const GatherArgs p) {
         }
         sn = nt;
       }
-      float* sp = reinterpret_cast<float*>(smem + SM::kRing + (i & 1) * SM::kOut);      // [4 waves][BN][3]
-      static_assert(4 * BN * 3 * 4 <= SM::kOut, "statistics scratch must fit in a staging tile");
+      RAW_BARRIER();                                         // everyone is done reading the staged tile (reads were waited for above)
+      static_assert(NW * BN * 3 * 4 <= SM::kStage, "statistics scratch must fit in a ring slot");      // [NW][BN][3] floats
       if (lane < CPR) {
 #pragma unroll
         for (int e = 0; e < CH; ++e) {
-          float* q = sp + ((size_t)(wave - 4) * BN + ec * CH + e) * 3;
-          q[0] = sn; q[1] = smean[e]; q[2] = sm2[e];
+          const unsigned qa = outs + (unsigned)(((wave * BN + ec * CH + e) * 3) * 4);
+          lds_write4(qa, sn); lds_write4(qa + 4, smean[e]); lds_write4(qa + 8, sm2[e]);
         }
       }
-      sn = 0.f;
-#pragma unroll
-      for (int e = 0; e < CH; ++e) { smean[e] = 0.f; sm2[e] = 0.f; }
       LDS_WAIT_ALL();
-    }
-  };
-  auto stats_fold = [&](int i) {
-    if constexpr (stats) {
-      int tm, tn; tile_coords(i, tm, tn);
-      const float* sp = reinterpret_cast<const float*>(smem + SM::kRing + (i & 1) * SM::kOut);
-      if (et < BN && tn * BN + et < p.Nout) {
-        float n = 0.f, mean = 0.f, m2 = 0.f;
+      RAW_BARRIER();
+      if (t < BN && n0 + t < p.Nout) {
+        float qn[NW], qm[NW], qv[NW];
 #pragma unroll
-        for (int w = 0; w < 4; ++w) {
-          const float* q = sp + ((size_t)w * BN + et) * 3;
-          const float nb = q[0];
-          if (nb > 0.f) { const float nt = n + nb, f = nb / nt, d = q[1] - mean; mean += d * f; m2 += q[2] + d * d * n * f; n = nt; }
+        for (int w = 0; w < NW; ++w) {
+          const unsigned qa = outs + (unsigned)(((w * BN + t) * 3) * 4);
+          qn[w] = lds_read4(qa); qm[w] = lds_read4(qa + 4); qv[w] = lds_read4(qa + 8);
         }
-        float* out = p.stat_partial + ((size_t)tm * p.Nout + tn * BN + et) * 3;
-        out[0] = n; out[1] = mean; out[2] = m2;
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(qn[0]), "+v"(qn[1]), "+v"(qn[2]), "+v"(qn[3]), "+v"(qm[0]), "+v"(qm[1]), "+v"(qm[2]),
+                     "+v"(qm[3]), "+v"(qv[0]), "+v"(qv[1]), "+v"(qv[2]), "+v"(qv[3]));
+        float cn = 0.f, mean = 0.f, m2 = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) {
+          const float nb = qn[w];
+          if (nb > 0.f) { const float nt = cn + nb, f = nb / nt, d = qm[w] - mean; mean += d * f; m2 += qv[w] + d * d * cn * f; cn = nt; }
+        }
+        float* out = p.stat_partial + ((size_t)tm * p.Nout + n0 + t) * 3;
+        out[0] = cn; out[1] = mean; out[2] = m2;
       }
     }
   };
 
-  // virtual steps v = 0 .. total + nk: barrier v is shared with the MFMA waves for v <= total (they leave after barrier `total`)
-  for (int v = 0; v <= total + nk; ++v) {
-    PG_STAMP(1, v, 0);
-    RAW_BARRIER();
-    PG_STAMP(1, v, 1);
-    const int q = v / nk, kt = v - q * nk;
-    const int ta = q - 1;                                    // the tile staged before barrier q * nk
-    if (ta >= 0 && ta < my_tiles) {
-      if (kt < nk - 1) { const int k0 = kt * Q, k1 = k0 + Q < IT ? k0 + Q : IT; if (k0 < IT) drain(ta, k0, k1); }
-      else stats_scratch(ta);
+  // ---- the pipeline
+  set_issue_tile(0);
+#pragma unroll
+  for (int d = 0; d < DIST; ++d)
+    if (is_gs < total) issue();
+  int kt = 0, tile_i = 0;
+  for (int gs = 0; gs < total; ++gs) {
+    // this wave's pieces of stage gs have landed once at most the pieces of the DIST-1 younger stages are outstanding
+    // (LDS-DMA, loads and stores retire in issue order; anything the epilogue issued meanwhile is younger still: waiting for
+    // more than needed is safe, never for less)
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (gs + DIST - 1 < total && DIST > 1) {
+      if constexpr ((DIST - 1) * (PA + PB) == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else if constexpr ((DIST - 1) * (PA + PB) == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      else if constexpr ((DIST - 1) * (PA + PB) == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else if constexpr ((DIST - 1) * (PA + PB) == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+      else if constexpr ((DIST - 1) * (PA + PB) == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
-    if (kt == 0 && q - 2 >= 0 && q - 2 < my_tiles) stats_fold(q - 2);
-    PG_STAMP(1, v, 2);
+#endif
+    RAW_BARRIER();                                           // everyone's pieces have; slot (gs - 1) % NS is no longer read
+    if (is_gs < total) issue();                              // stage gs + DIST -> the slot stage gs - 1 has just left
+    const unsigned as = smem_base + (unsigned)((gs % NS) * SM::kStage);
+    __builtin_amdgcn_s_setprio(1);
+    compute(as, __builtin_amdgcn_readfirstlane(kt == 0 ? 1 : 0));
+    __builtin_amdgcn_s_setprio(0);
+    if (++kt == nk) {
+      const int lin = tile_i * G + pos, tm = lin / ntn, tn = lin - tm * ntn;
+      epilogue(as, tm, tn);
+      kt = 0; ++tile_i;
+    }
   }
 }
 
@@ -432,7 +426,7 @@ static void launch_pgemm_epi(GatherArgs& a, int grid, hipStream_t st) {
   auto kern = pgemm_kernel<BM, BN, NS, EPI>;
   static bool attr_set = false;
   if (!attr_set) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem); attr_set = true; }
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), smem, st, a);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), smem, st, a);
 }
 template <int BM, int BN, int NS>
 static void launch_pgemm(GatherArgs& a, int ncu, hipStream_t st) {
@@ -446,7 +440,7 @@ static void launch_pgemm(GatherArgs& a, int ncu, hipStream_t st) {
     else a.stat_partial = nullptr;
   }
   constexpr int per_cu_lds = (160 * 1024) / PgSmem<BM, BN, NS>::kBytes;  // blocks that fit a CU's LDS
-  constexpr int per_cu = per_cu_lds < 2 ? per_cu_lds : 2;                 // ... and its registers (512-thread blocks)
+  constexpr int per_cu = per_cu_lds < 4 ? per_cu_lds : 4;
   static const int cap = getenv("MI355_PG_PER_CU") ? atoi(getenv("MI355_PG_PER_CU")) : 8;
   int grid = ncu * (per_cu < cap ? per_cu : cap);
   if (grid > a.ntiles) grid = a.ntiles;
@@ -455,28 +449,39 @@ static void launch_pgemm(GatherArgs& a, int ncu, hipStream_t st) {
 }
 
 // Does the launch described by `a` (filled as for dispatch_gather) fit this kernel?  1x1, unit stride both ways (GEMM rows =
-// NHWC pixels in order), bf16, whole 64-channel K steps and at least two of them, no BatchNorm-backward epilogue, no heat-map
-// output.
+// NHWC pixels in order), bf16, whole 64-channel K steps, no BatchNorm-backward epilogue, no heat-map output.
+static int g_pgemm_mode = -1;        // run-time switch (mi355_set_pgemm); -1: the environment decides (MI355_PGEMM, default 0)
+// 0: never; 1: where it measured faster than the gather kernel (below); 2: wherever the launch fits the kernel (tests, A/B runs).
+// Returns the previous setting.
+extern "C" int mi355_set_pgemm(int mode) {
+  const int prev = g_pgemm_mode;
+  g_pgemm_mode = mode < 0 ? -1 : (mode > 2 ? 2 : mode);
+  return prev;
+}
 bool pgemm_eligible(const GatherArgs& a, int elem_size) {
-  static const int on = getenv("MI355_PGEMM") ? atoi(getenv("MI355_PGEMM")) : 1;
-  if (!on || elem_size != 2) return false;
+  static const int env_mode = getenv("MI355_PGEMM") ? atoi(getenv("MI355_PGEMM")) : 0;
+  const int mode = g_pgemm_mode >= 0 ? g_pgemm_mode : env_mode;
+  if (!mode || elem_size != 2) return false;
   if (a.nphase != 1 || a.ph[0].ntaps != 1) return false;
   const Tap& tp = a.taps[a.ph[0].tap0];
   if (tp.dy != 0 || tp.dx != 0 || tp.widx != 0) return false;
   if (a.in_sx != 1 || a.in_sy != 1 || a.out_sx != 1 || a.out_sy != 1) return false;
   if (a.ph[0].OHp != a.Hi || a.ph[0].OWp != a.Wi || a.Ho != a.Hi || a.Wo != a.Wi || a.ph[0].out_oy || a.ph[0].out_ox) return false;
-  if (a.Ci % 64 || a.Ci < 128 || a.ldb != a.Ci || a.ldd != a.Nout || a.Nout % 8) return false;      // (two K steps at least: kernel schedule)
+  if (a.Ci % 64 || a.ldb != a.Ci || a.ldd != a.Nout || a.Nout % 8) return false;
   if (a.bnb_partial || a.hw) return false;
   const long Mrows = a.ph[0].M;
   if (Mrows * a.Ci * 2 >= (1L << 31) || Mrows * a.Nout * 2 >= (1L << 31)) return false;
-  static const int min_rows = getenv("MI355_PGEMM_MIN_ROWS") ? atoi(getenv("MI355_PGEMM_MIN_ROWS")) : 256;
-  return Mrows >= min_rows;
+  if (Mrows < 256) return false;
+  if (mode >= 2) return true;
+  // Where it wins (profiles/r03_pgemm_phases.txt, graph-timed per layer): not with the BatchNorm-statistics epilogue (one or two
+  // blocks per CU cannot hide its VALU work behind other blocks' MFMAs as the gather kernel's three or four do); otherwise on
+  // K-heavy layers, narrow outputs and small row counts; K = 64 .. 256 with wide outputs and many rows is HBM-bound on both
+  // kernels and the gather kernel's higher occupancy keeps more bytes in flight there.
+  if (a.stat_partial) return false;
+  return a.Ci >= 512 || a.Nout <= 64 || Mrows <= 16384;
 }
 
 int dispatch_pgemm(GatherArgs& a, hipStream_t st) {
-  static const int dbg = getenv("MI355_PG_DEBUG") ? atoi(getenv("MI355_PG_DEBUG")) : 0;      // diagnostic timing runs: results are wrong
-  a.hw = dbg;
-  if (dbg & 8) a.bnb_partial = reinterpret_cast<float*>(strtoull(getenv("MI355_PG_DEBUG_PTR") ? getenv("MI355_PG_DEBUG_PTR") : "0", nullptr, 0));
   static int ncu = 0;
   if (!ncu) {
     int dev = 0, v = 0;

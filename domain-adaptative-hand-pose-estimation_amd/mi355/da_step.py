@@ -344,6 +344,30 @@ class DAStep:
         self.graphs = graphs          # capturing executes nothing: model / optimizer state is unchanged
         return self
 
+    def choose_launch_mode(self, batch, after=None, threshold=0.95):
+        """Multi-rank runs: eager launches keep the gradient exchange overlapped with the backward, but only pay off while the
+        host can feed the GPU.  Times one eager iteration on the host (enqueue) and on the GPU (enqueue + drain); if enqueueing
+        takes (nearly) as long as running it on ANY rank, every rank should replay graphs instead (collectives between the
+        graphs).  Runs one real iteration (`after()` is called behind it: scheduler ticks) and returns 'graph' or 'eager' --
+        the same answer on every rank (MAX over ranks).  MI355_DDP_GRAPH=1 / 0 forces the answer."""
+        import time
+        forced = os.environ.get('MI355_DDP_GRAPH')
+        torch.cuda.synchronize()
+        t_a = time.perf_counter()
+        self.run(batch)
+        if after is not None:
+            after()
+        t_host = time.perf_counter() - t_a
+        torch.cuda.synchronize()
+        t_gpu = time.perf_counter() - t_a
+        r = torch.tensor([t_host / max(t_gpu, 1e-9)], device=next(self.model.parameters()).device)
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            dist.all_reduce(r, op=dist.ReduceOp.MAX)
+        self.host_gpu_ratio = float(r)
+        if forced in ('0', '1'):
+            return 'graph' if forced == '1' else 'eager'
+        return 'graph' if self.host_gpu_ratio > threshold else 'eager'
+
     def _host_tick(self):
         for o in self.opt.values():
             if hasattr(o, 'sync_lr'):

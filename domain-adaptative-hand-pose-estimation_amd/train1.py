@@ -299,13 +299,26 @@ def train(train_source_iter, train_target_iter, step, scheds, epoch, args):
         to = lambda t: t.to(device, non_blocking=True)
         batch = dict(x_s=to(x_s), label_s=to(label_s), w_s=to(weight_s), x_t=to(x_t), w_t=to(weight_t), label_t=to(label_t))
         meters[1].update(time.time() - end)
-        # HIP-graph replay once this process has run three eager iterations (whatever epoch it resumed at); with several
-        # ranks the eager path stays: its gradient exchange overlaps the backward, graph replay would serialise it
+        # HIP-graph replay once this process has run three eager iterations (whatever epoch it resumed at).  With several
+        # ranks the eager path overlaps the gradient exchange with the backward, which only pays while the host can enqueue an
+        # iteration faster than the GPU runs it: the fourth iteration is timed on host and GPU and every rank takes the same
+        # decision (DAStep.choose_launch_mode, the rule bench.py uses; MI355_DDP_GRAPH=1 / 0 forces it)
         step.eager_iters = getattr(step, 'eager_iters', 0)
-        if step.graphs is None and not args.no_graph and (WORLD == 1 or os.environ.get('MI355_DDP_GRAPH') == '1'):
-            if step.eager_iters == 3:
-                step.capture(batch, warmup=0)
-                print('HIP graphs captured: iterations replay six graphs from here on')
+        if step.graphs is None and not args.no_graph and step.eager_iters == 3 and not getattr(step, 'mode_chosen', False):
+            step.mode_chosen = True
+            mode = 'graph'
+            if WORLD > 1:
+                mode = step.choose_launch_mode(batch, after=lambda: [s.step() for s in scheds.values()])
+                print('multi-rank launch mode: host / GPU time of an eager iteration %.2f -> %s'
+                      % (step.host_gpu_ratio, 'HIP-graph replay, collectives between the graphs' if mode == 'graph'
+                         else 'eager launches, gradient exchange overlapped with the backward'))
+                step.eager_iters += 1
+                end = time.time()
+                if mode == 'graph':
+                    step.capture(batch, warmup=0)
+                continue                                      # (the timed iteration was a real one)
+            step.capture(batch, warmup=0)
+            print('HIP graphs captured: iterations replay six graphs from here on')
         elif step.graphs is None and step.eager_iters == 0:
             print('eager kernel launches%s' % (' with the gradient exchange overlapped with the backward' if WORLD > 1 else ''))
         step.eager_iters += 1

@@ -71,6 +71,11 @@ int mi355_conv_fwd(const mi355_conv_desc* d, const void* x, const void* w, const
                    const void* residual, void* y, void* stream);
 int mi355_conv_dgrad(const mi355_conv_desc* d, const void* dy, const void* wT, const float* bias,
                      const float* scale_dev, int accumulate, void* dx, void* stream);
+/* 1x1 / unit-stride bf16 convs (forward and input gradient) can run on a second kernel, the persistent pipelined GEMM of
+ * csrc/pgemm.hip (same results bit for bit): mode 0 never (default: end to end it measured no gain), 1 where
+ * it was faster per layer in isolation, 2 wherever the launch fits it (tests / A-B runs), -1 back to the environment's choice
+ * (MI355_PGEMM).  Returns the previous setting. */
+int mi355_set_pgemm(int mode);
 /* Inference forms: y = act(conv(x) + bias + residual), dx = act(dgrad(dy) + bias) (the ConvTranspose2d forward), act = ReLU when
  * relu != 0.  The caller folds an eval-mode BatchNorm that follows into the operands (w * gamma / sqrt(var + eps) per output
  * channel, bias = beta - mean * that scale): conv -> BN -> (+identity) -> ReLU of resnet.py / pose_resnet2.py:33-41 /

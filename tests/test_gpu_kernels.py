@@ -190,6 +190,72 @@ def test_conv_kernels_give_the_same_bits_run_after_run(gpu, case):
         assert torch.equal(u, v), 'output %d differs between two runs' % i
 
 
+PGEMM_CASES = [
+    # N, Ci, H, W, Co : 1x1 / unit-stride layers; one case per tile choice of dispatch_pgemm, ragged rows / column tails, 1 .. 32 K steps
+    (3, 128, 8, 8, 256),        # 192 rows: below the kernel's floor -> stays on the gather kernel whatever the mode (control)
+    (3, 64, 9, 13, 256),        # 351 rows (ragged: partial row tiles), one K step, 64 x 64 tiles
+    (4, 128, 16, 16, 64),       # two K steps, narrow output
+    (64, 1024, 16, 16, 256),    # 16 K steps, 64 x 128 tiles, two blocks per CU, one tile per block
+    (64, 256, 16, 16, 1024),    # 128 x 128 tiles, four tiles per persistent block
+    (16, 64, 64, 64, 64),       # 65536 rows, 128 x 64 tiles, many tiles per block
+    (64, 2048, 8, 8, 512),      # 32 K steps
+]
+
+
+@pytest.mark.parametrize('case', PGEMM_CASES)
+def test_pgemm_matches_the_gather_kernel_bit_for_bit(gpu, case):
+    """The persistent pipelined GEMM (csrc/pgemm.hip) and the gather kernel run the same MFMA sequence per output element: every
+    epilogue form must give IDENTICAL bits on both (forward plain / bias / bias + residual + ReLU, input gradient plain / scaled
+    accumulate / bit-masked accumulate); the fused BatchNorm statistics must agree per channel once folded; and the forward
+    must agree with a torch matmul within the bf16 tolerance."""
+    import mi355
+    ops = _ops()
+    lib = mi355.load()
+    N, Ci, H, W, Co = case
+    dt = torch.bfloat16
+    desc = ops.make_desc(N, H, W, Ci, Co, 1, 1, 1, 0, dt)
+    g = torch.Generator(device='cpu').manual_seed(31 + Ci + Co)
+    wm = (torch.randn(Co, 1, 1, Ci, generator=g) * 0.05).to(gpu)
+    wf, wt = ops.pack_weights(wm, Co, 1, Ci, Ci, dt)
+    x = ops.nhwc_empty(N, Ci, H, W, dt, gpu).normal_()
+    dy = ops.nhwc_empty(N, Co, H, W, dt, gpu).normal_()
+    res = ops.nhwc_empty(N, Co, H, W, dt, gpu).normal_()
+    base = ops.nhwc_empty(N, Ci, H, W, dt, gpu).normal_()
+    bias = torch.randn(Co, generator=g).to(gpu)
+    mask = torch.randint(0, 256, (N * H * W * Ci // 8,), dtype=torch.uint8, device=gpu)
+    sc = torch.tensor(0.25, device=gpu)
+    M = N * H * W
+
+    def run():
+        out = [ops.conv_fwd(desc, x, wf), ops.conv_fwd(desc, x, wf, bias), ops.conv_fwd(desc, x, wf, bias, res, relu=True)]
+        y, part = ops.conv_fwd_stats(desc, x, wf, None)
+        pr = part[0][:part[1] * Co * 3].view(part[1], Co, 3).double()
+        n, mean, m2 = pr[..., 0], pr[..., 1], pr[..., 2]
+        tot = n.sum(0); gm = (n * mean).sum(0) / tot
+        var = (m2 + n * (mean - gm) ** 2).sum(0) / tot
+        out += [y, ops.conv_dgrad(desc, dy, wt), ops.conv_dgrad(desc, dy, wt, scale_dev=sc, out=base.clone(), accumulate=True),
+                ops.conv_dgrad_masked_acc(desc, dy, wt, base.clone(), mask)]
+        torch.cuda.synchronize()
+        return out, (tot, gm, var)
+    prev = lib.mi355_set_pgemm(0)
+    try:
+        ref, st_ref = run()
+        lib.mi355_set_pgemm(2)
+        got, st_got = run()
+        got2, _ = run()
+    finally:
+        lib.mi355_set_pgemm(prev)
+    for i, (a, b, c) in enumerate(zip(ref, got, got2)):
+        assert torch.equal(a, b), 'output %d: pgemm differs from the gather kernel' % i
+        assert torch.equal(b, c), 'output %d: pgemm differs between two runs' % i
+    assert torch.equal(st_ref[0], st_got[0]) and float(st_got[0][0]) == M
+    assert float((st_ref[1] - st_got[1]).abs().max()) <= 1e-5 * (float(st_ref[1].abs().max()) + 1)
+    assert float((st_ref[2] - st_got[2]).abs().max()) <= 1e-4 * float(st_ref[2].abs().max())
+    yref = x.permute(0, 2, 3, 1).reshape(M, Ci).float() @ wm.reshape(Co, Ci).to(dt).float().t()
+    err = (got[0].permute(0, 2, 3, 1).reshape(M, Co).float() - yref).abs().max()
+    assert float(err) <= 1.2e-2 * float(yref.abs().max())
+
+
 STAT_CASES = [
     # kind, N, Ci, H, W, Co, k, s, p   (kind 'conv': Conv2d; 'deconv': conv-form of ConvTranspose2d(Co -> Ci, 4, 2, 1))
     ('conv', 2, 64, 16, 16, 128, 3, 1, 1),
