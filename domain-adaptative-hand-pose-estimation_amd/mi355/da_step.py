@@ -46,16 +46,22 @@ def _reduce_mean_(t, async_op=False):
     return w, ((lambda: None) if avg else (lambda: t.div_(ws)))
 
 
+# MI355_DDP_FORCE_COLLECTIVES=1: issue every collective of the multi-rank path even in a one-rank group -- the only way to run
+# the RCCL calls (init, AVG all-reduce of flat gradient ranges, async work handles, broadcast of the conv-form views) on a
+# one-GPU box (tests/test_gpu_ddp.py::test_rccl_single_rank_smoke); a mean over one rank is the identity.
+_FORCE_COLLECTIVES = os.environ.get('MI355_DDP_FORCE_COLLECTIVES', '0') == '1'
+
+
+def _distributed():
+    return dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or _FORCE_COLLECTIVES)
+
+
 def _allreduce_mean(bufs):
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not _distributed():
         return
     for b in bufs:
         _, finish = _reduce_mean_(b)
         finish()
-
-
-def _distributed():
-    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
 
 
 class _OverlapReducer:
@@ -105,7 +111,7 @@ class _OverlapReducer:
 def broadcast_module(module, src=0):
     """Rank `src`'s parameters and buffers to every rank.  Conv weights are strided (conv-form) views: the collective
     runs on their dense memory-order view."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not _distributed():
         return
     for t in list(module.parameters()) + list(module.buffers()):
         d = t.data

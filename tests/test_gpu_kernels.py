@@ -62,6 +62,9 @@ CONV_CASES = [
     (2, 128, 32, 32, 256, 4, 2, 1),   # 4x4, two output-channel tiles x two input-channel tiles
     (32, 64, 64, 64, 256, 3, 1, 1),   # 2048 output tiles: the shared-A-tile (KW3) forward / dgrad kernel is chosen by default
     (64, 64, 64, 64, 256, 3, 1, 1),   # 4096 output tiles: its 256x128 macro-tile build
+    # variants only the benchmark's sizes select, against torch at full size (round-2 verdict, item 8)
+    (64, 256, 64, 64, 256, 3, 2, 1),  # wgrad_kw2 at stage size + 4-phase strided dgrad + LDS-DMA ring forward (3x3 s2 256->256 @64->32, B=64)
+    (64, 256, 16, 16, 256, 3, 1, 1),  # 256 tiles, K = 2304: the LDS-DMA ring on the mid-size layers (3x3 256->256 @16x16, B=64)
 ]
 
 
@@ -374,7 +377,8 @@ def test_bn_train_fwd_bwd(gpu, dt, shape, relu, res):
 
 
 @pytest.mark.parametrize('dt', ['f32', 'bf16'])
-@pytest.mark.parametrize('shape', [(64, 256, 16, 16), (64, 2048, 8, 8), (64, 128, 32, 32), (5, 192, 7, 9), (64, 512, 8, 8), (1, 64, 1, 3)])
+@pytest.mark.parametrize('shape', [(64, 256, 16, 16), (64, 2048, 8, 8), (64, 128, 32, 32), (5, 192, 7, 9), (64, 512, 8, 8), (1, 64, 1, 3),
+                                   (64, 256, 64, 64)])      # the last one: 134 MB in bf16, only partially LDS-resident
 @pytest.mark.parametrize('mode', ['plain', 'relu', 'relu_residual'])
 def test_bn_backward_one_launch_lds_resident(gpu, dt, shape, mode):
     """Tensors that fit the chip's LDS take the one-launch backward (csrc/bn.hip bn_bwd_resident_kernel): model-sized and
@@ -864,6 +868,50 @@ def test_pointwise_k2c_epilogue_bn_statistics(gpu, dt, shape):
     assert torch.allclose(ma, mb, rtol=1e-5, atol=1e-6) and torch.allclose(ia, ib, rtol=2e-5, atol=1e-6)
     assert torch.allclose(rma, rmb, rtol=1e-5, atol=1e-6) and torch.allclose(rva, rvb, rtol=2e-5, atol=1e-6)
     assert float((ya.float() - yb.float()).abs().max()) <= (2e-2 if dt == 'bf16' else 1e-4)
+
+
+def test_grouped_weight_gradients_of_a_resnet_stage_at_full_size(gpu):
+    """One wgrad_group launch of layer3's 1x1 convs at the benchmark's size (B=64, 16x16 maps, bf16), every problem against
+    torch's fp32 weight gradient on the same bf16-rounded operands (round-2 verdict, item 8)."""
+    ops = _ops()
+    tdt = torch.bfloat16
+    shapes = [(64, 16, 16, 1024, 256, 1, 1, 0), (64, 16, 16, 256, 1024, 1, 1, 0), (64, 32, 32, 512, 1024, 1, 2, 0), (64, 32, 32, 512, 256, 1, 1, 0)] * 2
+    items, refs = [], []
+    for i, (N, H, W, Ci, Co, k, s, p) in enumerate(shapes):
+        d = ops.make_desc(N, H, W, Ci, Co, k, k, s, p, tdt)
+        x = ops.nhwc_empty(N, Ci, H, W, tdt, gpu).normal_()
+        dy = ops.nhwc_empty(N, Co, d.Ho, d.Wo, tdt, gpu).normal_()
+        xs = x[:, :, ::s, ::s].permute(0, 2, 3, 1).reshape(-1, Ci).float()           # 1x1: dW[o][c] = sum_m dy[m][o] x[m*s][c]
+        refs.append((dy.permute(0, 2, 3, 1).reshape(-1, Co).float().t() @ xs).reshape(-1))
+        items.append((d, x, dy, torch.full((Co * Ci,), float('nan'), device=gpu), False))
+    ops.conv_wgrad_grouped(items)
+    torch.cuda.synchronize()
+    for i, ((d, x, dy, dw, acc), ref) in enumerate(zip(items, refs)):
+        assert torch.isfinite(dw).all(), i
+        assert float((dw - ref).abs().max()) <= 2e-3 * float(ref.abs().max()), (i, shapes[i])
+
+
+def test_grouped_weight_gradients_keep_the_order_of_items_that_share_a_gradient(gpu):
+    """One conv used twice in a backward hands the group two items with the SAME dw (overwrite, then accumulate): they must not
+    share a launch (the overwrite and the read-modify-write would race) and must keep their order (advisor, round 2)."""
+    ops = _ops()
+    tdt = torch.bfloat16
+    N, H, W, Ci, Co = 4, 16, 16, 64, 256
+    d = ops.make_desc(N, H, W, Ci, Co, 1, 1, 1, 0, tdt)
+    xs = [ops.nhwc_empty(N, Ci, H, W, tdt, gpu).normal_() for _ in range(2)]
+    dys = [ops.nhwc_empty(N, Co, H, W, tdt, gpu).normal_() for _ in range(2)]
+    other = ops.make_desc(2, 8, 8, 128, 512, 1, 1, 1, 0, tdt)
+    xo, dyo = ops.nhwc_empty(2, 128, 8, 8, tdt, gpu).normal_(), ops.nhwc_empty(2, 512, 8, 8, tdt, gpu).normal_()
+    dw = torch.full((Co * Ci,), float('nan'), device=gpu)
+    dwo = torch.full((512 * 128,), float('nan'), device=gpu)
+    ref = torch.empty(Co * Ci, device=gpu)
+    ops.conv_wgrad(d, xs[0], dys[0], ref, False); ops.conv_wgrad(d, xs[1], dys[1], ref, True)
+    for _ in range(3):
+        dw.fill_(float('nan'))
+        ops.conv_wgrad_grouped([(d, xs[0], dys[0], dw, False), (other, xo, dyo, dwo, False), (d, xs[1], dys[1], dw, True)])
+        torch.cuda.synchronize()
+        assert torch.isfinite(dw).all()
+        assert float((dw - ref).abs().max()) <= 1e-4 * float(ref.abs().max())
 
 
 @pytest.mark.parametrize('dt', ['f32', 'bf16'])
