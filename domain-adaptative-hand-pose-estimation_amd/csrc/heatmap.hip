@@ -2,6 +2,7 @@
 // fused log-softmax + KL loss (+ its gradient), pseudo-label builders, bilinear up-sampling, PCK distances.
 // One 256-thread workgroup per map, wave-shuffle reductions; all HBM/L2-bound.
 #include "common.h"
+#include <stdlib.h>
 
 struct ArgBest { float v; int i; };
 __device__ __forceinline__ bool arg_better(float av, int ai, float bv, int bi) {
@@ -90,6 +91,158 @@ __global__ __launch_bounds__(256) void kl_heatmap_kernel(const float* __restrict
   }
 }
 
+// ---------------------------------------------------------------------------------------- register-resident row kernels
+// The three row kernels above walk a map two to four times with 4-byte loads and a block reduction between the walks: at one
+// 16-KB map per workgroup they are latency-bound (arg-max 1.8 TB/s, soft-arg-max and KL 1.3 - 2 TB/s of the 22-MB heat-map
+// tensors by counters, round 2).  These forms fetch a map ONCE with 16-byte loads, all of them in flight together, and keep it
+// in registers for every pass:
+//   WPM = false: one 256-thread workgroup per map of 1024 * NV floats (64 x 64 maps: NV = 4), block reductions through LDS;
+//   WPM = true : one WAVE per map of 256 * NV floats (16 x 16: NV = 1, 32 x 32: NV = 4), four maps per workgroup, reductions by
+//                wave shuffles only -- no LDS, no barrier.
+// Same arithmetic per element as the kernels above; sums are folded in a different (fixed) order.
+template <int NV, bool WPM> struct RowGeom {
+  static constexpr int kThreads = WPM ? 64 : 256;                         // threads per map
+  __device__ static int map() { return WPM ? (int)(blockIdx.x * 4 + (threadIdx.x >> 6)) : (int)blockIdx.x; }
+  __device__ static int tid() { return WPM ? (int)(threadIdx.x & 63) : (int)threadIdx.x; }
+  __device__ static float sum(float v, float* red) { if constexpr (WPM) return wave_sum(v); else return block_sum<4>(v, red); }
+  __device__ static float max(float v, float* red) { if constexpr (WPM) return wave_max(v); else return block_max<4>(v, red); }
+};
+template <int NV, bool WPM>
+__device__ __forceinline__ void row_load(const float* __restrict__ row, float (&v)[4 * NV]) {
+  using G = RowGeom<NV, WPM>;
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    const float4 q = reinterpret_cast<const float4*>(row)[G::tid() + G::kThreads * j];
+    v[4 * j] = q.x; v[4 * j + 1] = q.y; v[4 * j + 2] = q.z; v[4 * j + 3] = q.w;
+  }
+}
+// element index of register slot (j, e) of this thread
+template <int NV, bool WPM> __device__ __forceinline__ int row_index(int j, int e) { return 4 * (RowGeom<NV, WPM>::tid() + RowGeom<NV, WPM>::kThreads * j) + e; }
+
+template <int NV, bool WPM>
+__global__ __launch_bounds__(256) void argmax2d_reg_kernel(const float* __restrict__ hm, int* __restrict__ idx, float* __restrict__ xy,
+                                                            float* __restrict__ maxval, int rows, int W) {
+  using G = RowGeom<NV, WPM>;
+  constexpr int HW = 4 * NV * G::kThreads;
+  __shared__ float sv[4]; __shared__ int si[4];
+  const int m = G::map();
+  if (WPM && m >= rows) return;                              // (wave-uniform: a whole wave owns a map)
+  float v[4 * NV];
+  row_load<NV, WPM>(hm + (size_t)m * HW, v);
+  float bv = v[0]; int bi = row_index<NV, WPM>(0, 0);
+#pragma unroll
+  for (int j = 0; j < NV; ++j)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { const int i = row_index<NV, WPM>(j, e); if (arg_better(v[4 * j + e], i, bv, bi)) { bv = v[4 * j + e]; bi = i; } }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ov = __shfl_xor(bv, o, 64); const int oi = __shfl_xor(bi, o, 64);
+    if (arg_better(ov, oi, bv, bi)) { bv = ov; bi = oi; }
+  }
+  if constexpr (!WPM) {
+    if ((threadIdx.x & 63) == 0) { sv[threadIdx.x >> 6] = bv; si[threadIdx.x >> 6] = bi; }
+    __syncthreads();
+    if (threadIdx.x == 0)
+      for (int w = 1; w < 4; ++w) if (arg_better(sv[w], si[w], bv, bi)) { bv = sv[w]; bi = si[w]; }
+  }
+  if (G::tid() == 0) {
+    const bool pos = bv > 0.0f;                              // np.greater(maxvals, 0.0): NaN -> False
+    if (idx) idx[m] = bi;
+    if (maxval) maxval[m] = bv;
+    if (xy) { xy[2 * m] = pos ? (float)(bi % W) : 0.f; xy[2 * m + 1] = pos ? (float)(bi / W) : 0.f; }
+  }
+}
+
+template <int NV, bool WPM>
+__global__ __launch_bounds__(256) void softargmax_reg_kernel(const float* __restrict__ hm, float* __restrict__ uv, int rows, int W, float beta,
+                                                              float out_scale) {
+  using G = RowGeom<NV, WPM>;
+  constexpr int HW = 4 * NV * G::kThreads;
+  __shared__ float red[4];
+  const int m = G::map();
+  if (WPM && m >= rows) return;
+  float v[4 * NV];
+  row_load<NV, WPM>(hm + (size_t)m * HW, v);
+  float mx = -INFINITY;
+#pragma unroll
+  for (int k = 0; k < 4 * NV; ++k) mx = fmaxf(mx, v[k] * beta);
+  mx = G::max(mx, red);
+  float s = 0.f, su = 0.f, sv = 0.f;
+#pragma unroll
+  for (int j = 0; j < NV; ++j)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int i = row_index<NV, WPM>(j, e);
+      const float ex = expf(v[4 * j + e] * beta - mx);
+      s += ex; su += ex * (float)(i % W); sv += ex * (float)(i / W);
+    }
+  s = G::sum(s, red); su = G::sum(su, red); sv = G::sum(sv, red);
+  if (G::tid() == 0) { uv[2 * m] = su / s * out_scale; uv[2 * m + 1] = sv / s * out_scale; }
+}
+
+template <int NV, bool WPM>
+__global__ __launch_bounds__(256) void kl_heatmap_reg_kernel(const float* __restrict__ pred, const float* __restrict__ target,
+                                                              const float* __restrict__ weight, float eps, float* __restrict__ loss_rows,
+                                                              float* __restrict__ unit_grad, int rows, float inv_count) {
+  using G = RowGeom<NV, WPM>;
+  constexpr int HW = 4 * NV * G::kThreads;
+  __shared__ float red[4];
+  const int m = G::map();
+  if (WPM && m >= rows) return;
+  const size_t base = (size_t)m * HW;
+  float p[4 * NV], t[4 * NV];
+  row_load<NV, WPM>(pred + base, p);
+  row_load<NV, WPM>(target + base, t);
+  float mx = -INFINITY, ts = 0.f;
+#pragma unroll
+  for (int k = 0; k < 4 * NV; ++k) { mx = fmaxf(mx, p[k]); ts += t[k] + eps; }
+  mx = G::max(mx, red);
+  ts = G::sum(ts, red);
+  float se = 0.f;
+#pragma unroll
+  for (int k = 0; k < 4 * NV; ++k) se += expf(p[k] - mx);
+  se = G::sum(se, red);
+  const float lse = logf(se);
+  float l = 0.f, tn_sum = 0.f;
+#pragma unroll
+  for (int k = 0; k < 4 * NV; ++k) {
+    const float tn = (t[k] + eps) / ts;
+    const float logp = p[k] - mx - lse;
+    const float xl = (tn == 0.f) ? 0.f : tn * logf(tn);      // nn.KLDivLoss pointwise: xlogy(t,t) - t*logp
+    l += xl - tn * logp;
+    tn_sum += tn;
+    t[k] = tn;                                               // (kept for the gradient)
+  }
+  l = G::sum(l, red);
+  tn_sum = G::sum(tn_sum, red);
+  const float w = weight ? weight[m] : 1.f;
+  if (G::tid() == 0) loss_rows[m] = l * w;
+  if (unit_grad) {
+    const float kk = w * inv_count;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      float4 g;
+      g.x = kk * (expf(p[4 * j] - mx - lse) * tn_sum - t[4 * j]);
+      g.y = kk * (expf(p[4 * j + 1] - mx - lse) * tn_sum - t[4 * j + 1]);
+      g.z = kk * (expf(p[4 * j + 2] - mx - lse) * tn_sum - t[4 * j + 2]);
+      g.w = kk * (expf(p[4 * j + 3] - mx - lse) * tn_sum - t[4 * j + 3]);
+      reinterpret_cast<float4*>(unit_grad + base)[G::tid() + G::kThreads * j] = g;
+    }
+  }
+}
+
+// row-kernel dispatch: 0 = no register form for this map size (or unaligned pointers): the loop kernels above
+static int row_form(int HW, const void* a, const void* b = nullptr, const void* c = nullptr) {
+  static const bool on = !(getenv("MI355_ROW_REG") && atoi(getenv("MI355_ROW_REG")) == 0);      // A/B switch
+  if (!on) return 0;
+  if (((uintptr_t)a | (uintptr_t)b | (uintptr_t)c) & 15) return 0;
+  static const bool wpm64 = getenv("MI355_ROW_WPM64") && atoi(getenv("MI355_ROW_WPM64")) == 1;      // experiment: wave per 64 x 64 map
+  if (HW == 4096) return wpm64 ? 4 : 1;       // block per map, 16 floats per thread (4: a wave per map, 64 floats per lane)
+  if (HW == 1024) return 2;       // wave per map, 16 floats per lane
+  if (HW == 256) return 3;        // wave per map, 4 floats per lane
+  return 0;
+}
+
 __global__ __launch_bounds__(256) void reduce_sum_kernel(const float* __restrict__ in, float* __restrict__ out, int n, float scale) {
   __shared__ float red[4];
   float s = 0.f;
@@ -163,6 +316,73 @@ __global__ __launch_bounds__(256) void pseudo_label_kernel(const float* __restri
   }
 }
 
+// register-resident form of pseudo_label_kernel for maps of 1024 * NV pixels (64 x 64: NV = 4, 32 x 32: NV = 1): the ground-false
+// values stay in registers between the clip and the per-map max-normalisation (the loop form writes them, then reads them back
+// and writes them again: 1.38x its algorithmic traffic by counters), every store is 16 bytes.  Same arithmetic per pixel.
+template <int NV>
+__global__ __launch_bounds__(256) void pseudo_label_reg_kernel(const float* __restrict__ xy, const float* __restrict__ patch, int radius, int div,
+                                                                int S, int kind, const float* __restrict__ extra, int normalise,
+                                                                float* __restrict__ gt, float* __restrict__ gf, int K) {
+  __shared__ int cx[64], cy[64];
+  __shared__ float spatch[13 * 13];
+  __shared__ float red[4];
+  const int b = blockIdx.x / K, k = blockIdx.x % K;
+  const int side = 2 * radius + 1;
+  if (threadIdx.x < K) {
+    const float x = xy[2 * (b * K + threadIdx.x)], y = xy[2 * (b * K + threadIdx.x) + 1];
+    cx[threadIdx.x] = (int)(x / (float)div); cy[threadIdx.x] = (int)(y / (float)div);   // .astype(int): truncation
+  }
+  for (int i = threadIdx.x; i < side * side; i += 256) spatch[i] = patch[i];
+  __syncthreads();
+  const size_t base = (size_t)blockIdx.x * S * S;
+  auto gauss = [&](int j, int px, int py) -> float {
+    const int dx = px - cx[j] + radius, dy = py - cy[j] + radius;
+    return (dx >= 0 && dx < side && dy >= 0 && dy < side) ? spatch[dy * side + dx] : 0.f;
+  };
+  float f[4 * NV];
+  float mx = -INFINITY;
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    const int v4 = threadIdx.x + 256 * j;
+    float4 ex = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (gf && extra) ex = reinterpret_cast<const float4*>(extra + base)[v4];
+    const float exv[4] = {ex.x, ex.y, ex.z, ex.w};
+    float g4[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int i = 4 * v4 + e, px = i % S, py = i / S;
+      const float g = gauss(k, px, py);
+      g4[e] = g;
+      float fv = 0.f;
+      if (gf) {
+        if (kind == 1) fv = fminf(fmaxf(1.f - g * 10.f, 0.f), 1.f);
+        else {
+          float s = 0.f;
+          if (kind == 0) { for (int q = 0; q < K; ++q) if (q != k) s += gauss(q, px, py); fv = fminf(fmaxf(s, 0.f), 1.f); }
+          else { for (int q = 0; q < K; ++q) s += gauss(q, px, py); fv = fminf(fmaxf(fminf(fmaxf(s, 0.f), 1.f) - g * 10.f, 0.f), 1.f); }
+        }
+        if (extra) fv = fminf(fmaxf(fv + exv[e] - g * 100.f, 0.f), 1.f);
+        mx = fmaxf(mx, fv);
+      }
+      f[4 * j + e] = fv;
+    }
+    if (gt) reinterpret_cast<float4*>(gt + base)[v4] = make_float4(g4[0], g4[1], g4[2], g4[3]);
+  }
+  if (!gf) return;
+  bool divide = false;
+  if (normalise) {
+    mx = block_max<4>(mx, red);
+    divide = !(normalise == 2 && !(mx > 0.f));               // guarded mode: an all-zero map stays zero (block-uniform)
+  }
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    float4 o;
+    o.x = divide ? f[4 * j] / mx : f[4 * j]; o.y = divide ? f[4 * j + 1] / mx : f[4 * j + 1];      // 0/0 -> NaN as the reference
+    o.z = divide ? f[4 * j + 2] / mx : f[4 * j + 2]; o.w = divide ? f[4 * j + 3] / mx : f[4 * j + 3];
+    reinterpret_cast<float4*>(gf + base)[threadIdx.x + 256 * j] = o;
+  }
+}
+
 // nn.Upsample(size, mode='bilinear'), align_corners=False (ATen upsample_bilinear2d index rule)
 __global__ void bilinear_up_kernel(const float* __restrict__ in, float* __restrict__ out, int rows, int h, int w, int H, int W,
                                    float alpha, int accumulate) {
@@ -199,20 +419,41 @@ __global__ void pck_dists_kernel(const float* __restrict__ pred, const float* __
 // ---------------------------------------------------------------------------------------- host
 extern "C" int mi355_argmax2d(const float* hm, int32_t* idx, float* xy, float* maxval, int rows, int H, int W, void* stream) {
   if (!hm || rows < 1 || H < 1 || W < 1) MI_FAIL(MI355_EINVAL, "argmax2d: bad args");
-  hipLaunchKernelGGL(argmax2d_kernel, dim3(rows), dim3(256), 0, as_stream(stream), hm, idx, xy, maxval, H * W, W);
+  hipStream_t st = as_stream(stream);
+  switch (row_form(H * W, hm)) {
+    case 1: hipLaunchKernelGGL((argmax2d_reg_kernel<4, false>), dim3(rows), dim3(256), 0, st, hm, idx, xy, maxval, rows, W); break;
+    case 2: hipLaunchKernelGGL((argmax2d_reg_kernel<4, true>), dim3(cdiv(rows, 4)), dim3(256), 0, st, hm, idx, xy, maxval, rows, W); break;
+    case 3: hipLaunchKernelGGL((argmax2d_reg_kernel<1, true>), dim3(cdiv(rows, 4)), dim3(256), 0, st, hm, idx, xy, maxval, rows, W); break;
+    case 4: hipLaunchKernelGGL((argmax2d_reg_kernel<16, true>), dim3(cdiv(rows, 4)), dim3(256), 0, st, hm, idx, xy, maxval, rows, W); break;
+    default: hipLaunchKernelGGL(argmax2d_kernel, dim3(rows), dim3(256), 0, st, hm, idx, xy, maxval, H * W, W);
+  }
   MI_CHECK_LAUNCH("argmax2d");
   return MI355_OK;
 }
 extern "C" int mi355_softargmax(const float* hm, float* uv, int rows, int H, int W, float beta, float out_scale, void* stream) {
   if (!hm || !uv || rows < 1 || H < 1 || W < 1) MI_FAIL(MI355_EINVAL, "softargmax: bad args");
-  hipLaunchKernelGGL(softargmax_kernel, dim3(rows), dim3(256), 0, as_stream(stream), hm, uv, H * W, W, beta, out_scale);
+  hipStream_t st = as_stream(stream);
+  switch (row_form(H * W, hm)) {
+    case 1: hipLaunchKernelGGL((softargmax_reg_kernel<4, false>), dim3(rows), dim3(256), 0, st, hm, uv, rows, W, beta, out_scale); break;
+    case 2: hipLaunchKernelGGL((softargmax_reg_kernel<4, true>), dim3(cdiv(rows, 4)), dim3(256), 0, st, hm, uv, rows, W, beta, out_scale); break;
+    case 3: hipLaunchKernelGGL((softargmax_reg_kernel<1, true>), dim3(cdiv(rows, 4)), dim3(256), 0, st, hm, uv, rows, W, beta, out_scale); break;
+    case 4: hipLaunchKernelGGL((softargmax_reg_kernel<16, true>), dim3(cdiv(rows, 4)), dim3(256), 0, st, hm, uv, rows, W, beta, out_scale); break;
+    default: hipLaunchKernelGGL(softargmax_kernel, dim3(rows), dim3(256), 0, st, hm, uv, H * W, W, beta, out_scale);
+  }
   MI_CHECK_LAUNCH("softargmax");
   return MI355_OK;
 }
 extern "C" int mi355_kl_heatmap(const float* pred, const float* target, const float* weight, float eps, float* loss_rows,
                                 float* unit_grad, int rows, int HW, float inv_count, void* stream) {
   if (!pred || !target || !loss_rows || rows < 1 || HW < 1) MI_FAIL(MI355_EINVAL, "kl_heatmap: bad args");
-  hipLaunchKernelGGL(kl_heatmap_kernel, dim3(rows), dim3(256), 0, as_stream(stream), pred, target, weight, eps, loss_rows, unit_grad, HW, inv_count);
+  hipStream_t st = as_stream(stream);
+  switch (row_form(HW, pred, target, unit_grad)) {
+    case 1: hipLaunchKernelGGL((kl_heatmap_reg_kernel<4, false>), dim3(rows), dim3(256), 0, st, pred, target, weight, eps, loss_rows, unit_grad, rows, inv_count); break;
+    case 2: hipLaunchKernelGGL((kl_heatmap_reg_kernel<4, true>), dim3(cdiv(rows, 4)), dim3(256), 0, st, pred, target, weight, eps, loss_rows, unit_grad, rows, inv_count); break;
+    case 3: hipLaunchKernelGGL((kl_heatmap_reg_kernel<1, true>), dim3(cdiv(rows, 4)), dim3(256), 0, st, pred, target, weight, eps, loss_rows, unit_grad, rows, inv_count); break;
+    case 4: hipLaunchKernelGGL((kl_heatmap_reg_kernel<16, true>), dim3(cdiv(rows, 4)), dim3(256), 0, st, pred, target, weight, eps, loss_rows, unit_grad, rows, inv_count); break;
+    default: hipLaunchKernelGGL(kl_heatmap_kernel, dim3(rows), dim3(256), 0, st, pred, target, weight, eps, loss_rows, unit_grad, HW, inv_count);
+  }
   MI_CHECK_LAUNCH("kl_heatmap");
   return MI355_OK;
 }
@@ -246,7 +487,10 @@ extern "C" int mi355_pseudo_label(const float* xy, const float* patch, int radiu
                                   int normalise, float* gt, float* gf, int B, int K, void* stream) {
   if (!xy || !patch || radius < 0 || radius > 6 || div < 1 || S < 1 || kind < 0 || kind > 2 || B < 1 || K < 1 || K > 64)
     MI_FAIL(MI355_EINVAL, "pseudo_label: bad args (radius=%d div=%d S=%d kind=%d B=%d K=%d)", radius, div, S, kind, B, K);
-  hipLaunchKernelGGL(pseudo_label_kernel, dim3(B * K), dim3(256), 0, as_stream(stream), xy, patch, radius, div, S, kind, extra, normalise, gt, gf, K);
+  const int form = row_form(S * S, extra, gt, gf);
+  if (form == 1 || form == 4) hipLaunchKernelGGL(pseudo_label_reg_kernel<4>, dim3(B * K), dim3(256), 0, as_stream(stream), xy, patch, radius, div, S, kind, extra, normalise, gt, gf, K);
+  else if (form == 2) hipLaunchKernelGGL(pseudo_label_reg_kernel<1>, dim3(B * K), dim3(256), 0, as_stream(stream), xy, patch, radius, div, S, kind, extra, normalise, gt, gf, K);
+  else hipLaunchKernelGGL(pseudo_label_kernel, dim3(B * K), dim3(256), 0, as_stream(stream), xy, patch, radius, div, S, kind, extra, normalise, gt, gf, K);
   MI_CHECK_LAUNCH("pseudo_label");
   return MI355_OK;
 }
