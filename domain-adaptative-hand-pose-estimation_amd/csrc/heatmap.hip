@@ -106,6 +106,16 @@ template <int NV, bool WPM> struct RowGeom {
   __device__ static int tid() { return WPM ? (int)(threadIdx.x & 63) : (int)threadIdx.x; }
   __device__ static float sum(float v, float* red) { if constexpr (WPM) return wave_sum(v); else return block_sum<4>(v, red); }
   __device__ static float max(float v, float* red) { if constexpr (WPM) return wave_max(v); else return block_max<4>(v, red); }
+  // three sums with ONE exchange through LDS (red3: 12 floats) instead of three barrier pairs
+  __device__ static void sum3(float& a, float& b, float& c, float* red3) {
+    a = wave_sum(a); b = wave_sum(b); c = wave_sum(c);
+    if constexpr (!WPM) {
+      __syncthreads();
+      if ((threadIdx.x & 63) == 0) { float* q = red3 + 3 * (threadIdx.x >> 6); q[0] = a; q[1] = b; q[2] = c; }
+      __syncthreads();
+      a = (red3[0] + red3[3]) + (red3[6] + red3[9]); b = (red3[1] + red3[4]) + (red3[7] + red3[10]); c = (red3[2] + red3[5]) + (red3[8] + red3[11]);
+    }
+  }
 };
 template <int NV, bool WPM>
 __device__ __forceinline__ void row_load(const float* __restrict__ row, float (&v)[4 * NV]) {
@@ -176,7 +186,8 @@ __global__ __launch_bounds__(256) void softargmax_reg_kernel(const float* __rest
       const float ex = expf(v[4 * j + e] * beta - mx);
       s += ex; su += ex * (float)(i % W); sv += ex * (float)(i / W);
     }
-  s = G::sum(s, red); su = G::sum(su, red); sv = G::sum(sv, red);
+  __shared__ float red3[12];
+  G::sum3(s, su, sv, red3);
   if (G::tid() == 0) { uv[2 * m] = su / s * out_scale; uv[2 * m + 1] = sv / s * out_scale; }
 }
 
@@ -236,8 +247,8 @@ static int row_form(int HW, const void* a, const void* b = nullptr, const void* 
   static const bool on = !(getenv("MI355_ROW_REG") && atoi(getenv("MI355_ROW_REG")) == 0);      // A/B switch
   if (!on) return 0;
   if (((uintptr_t)a | (uintptr_t)b | (uintptr_t)c) & 15) return 0;
-  static const bool wpm64 = getenv("MI355_ROW_WPM64") && atoi(getenv("MI355_ROW_WPM64")) == 1;      // experiment: wave per 64 x 64 map
-  if (HW == 4096) return wpm64 ? 4 : 1;       // block per map, 16 floats per thread (4: a wave per map, 64 floats per lane)
+  if (HW == 4096) return 1;       // block per map, 16 floats per thread (a wave per 64 x 64 map, 64 floats per lane, measured slower:
+                                  // arg-max 9.5 vs 6.5 us, soft-arg-max 12.4 vs 8.7, KL 22.5 vs 18.1 on the 64 x 21 x 64 x 64 tensor)
   if (HW == 1024) return 2;       // wave per map, 16 floats per lane
   if (HW == 256) return 3;        // wave per map, 4 floats per lane
   return 0;
@@ -424,7 +435,6 @@ extern "C" int mi355_argmax2d(const float* hm, int32_t* idx, float* xy, float* m
     case 1: hipLaunchKernelGGL((argmax2d_reg_kernel<4, false>), dim3(rows), dim3(256), 0, st, hm, idx, xy, maxval, rows, W); break;
     case 2: hipLaunchKernelGGL((argmax2d_reg_kernel<4, true>), dim3(cdiv(rows, 4)), dim3(256), 0, st, hm, idx, xy, maxval, rows, W); break;
     case 3: hipLaunchKernelGGL((argmax2d_reg_kernel<1, true>), dim3(cdiv(rows, 4)), dim3(256), 0, st, hm, idx, xy, maxval, rows, W); break;
-    case 4: hipLaunchKernelGGL((argmax2d_reg_kernel<16, true>), dim3(cdiv(rows, 4)), dim3(256), 0, st, hm, idx, xy, maxval, rows, W); break;
     default: hipLaunchKernelGGL(argmax2d_kernel, dim3(rows), dim3(256), 0, st, hm, idx, xy, maxval, H * W, W);
   }
   MI_CHECK_LAUNCH("argmax2d");
@@ -437,7 +447,6 @@ extern "C" int mi355_softargmax(const float* hm, float* uv, int rows, int H, int
     case 1: hipLaunchKernelGGL((softargmax_reg_kernel<4, false>), dim3(rows), dim3(256), 0, st, hm, uv, rows, W, beta, out_scale); break;
     case 2: hipLaunchKernelGGL((softargmax_reg_kernel<4, true>), dim3(cdiv(rows, 4)), dim3(256), 0, st, hm, uv, rows, W, beta, out_scale); break;
     case 3: hipLaunchKernelGGL((softargmax_reg_kernel<1, true>), dim3(cdiv(rows, 4)), dim3(256), 0, st, hm, uv, rows, W, beta, out_scale); break;
-    case 4: hipLaunchKernelGGL((softargmax_reg_kernel<16, true>), dim3(cdiv(rows, 4)), dim3(256), 0, st, hm, uv, rows, W, beta, out_scale); break;
     default: hipLaunchKernelGGL(softargmax_kernel, dim3(rows), dim3(256), 0, st, hm, uv, H * W, W, beta, out_scale);
   }
   MI_CHECK_LAUNCH("softargmax");
@@ -451,7 +460,6 @@ extern "C" int mi355_kl_heatmap(const float* pred, const float* target, const fl
     case 1: hipLaunchKernelGGL((kl_heatmap_reg_kernel<4, false>), dim3(rows), dim3(256), 0, st, pred, target, weight, eps, loss_rows, unit_grad, rows, inv_count); break;
     case 2: hipLaunchKernelGGL((kl_heatmap_reg_kernel<4, true>), dim3(cdiv(rows, 4)), dim3(256), 0, st, pred, target, weight, eps, loss_rows, unit_grad, rows, inv_count); break;
     case 3: hipLaunchKernelGGL((kl_heatmap_reg_kernel<1, true>), dim3(cdiv(rows, 4)), dim3(256), 0, st, pred, target, weight, eps, loss_rows, unit_grad, rows, inv_count); break;
-    case 4: hipLaunchKernelGGL((kl_heatmap_reg_kernel<16, true>), dim3(cdiv(rows, 4)), dim3(256), 0, st, pred, target, weight, eps, loss_rows, unit_grad, rows, inv_count); break;
     default: hipLaunchKernelGGL(kl_heatmap_kernel, dim3(rows), dim3(256), 0, st, pred, target, weight, eps, loss_rows, unit_grad, HW, inv_count);
   }
   MI_CHECK_LAUNCH("kl_heatmap");
@@ -488,7 +496,7 @@ extern "C" int mi355_pseudo_label(const float* xy, const float* patch, int radiu
   if (!xy || !patch || radius < 0 || radius > 6 || div < 1 || S < 1 || kind < 0 || kind > 2 || B < 1 || K < 1 || K > 64)
     MI_FAIL(MI355_EINVAL, "pseudo_label: bad args (radius=%d div=%d S=%d kind=%d B=%d K=%d)", radius, div, S, kind, B, K);
   const int form = row_form(S * S, extra, gt, gf);
-  if (form == 1 || form == 4) hipLaunchKernelGGL(pseudo_label_reg_kernel<4>, dim3(B * K), dim3(256), 0, as_stream(stream), xy, patch, radius, div, S, kind, extra, normalise, gt, gf, K);
+  if (form == 1) hipLaunchKernelGGL(pseudo_label_reg_kernel<4>, dim3(B * K), dim3(256), 0, as_stream(stream), xy, patch, radius, div, S, kind, extra, normalise, gt, gf, K);
   else if (form == 2) hipLaunchKernelGGL(pseudo_label_reg_kernel<1>, dim3(B * K), dim3(256), 0, as_stream(stream), xy, patch, radius, div, S, kind, extra, normalise, gt, gf, K);
   else hipLaunchKernelGGL(pseudo_label_kernel, dim3(B * K), dim3(256), 0, as_stream(stream), xy, patch, radius, div, S, kind, extra, normalise, gt, gf, K);
   MI_CHECK_LAUNCH("pseudo_label");
