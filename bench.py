@@ -80,16 +80,18 @@ def host_cores():
 
 
 def pmc_record(args):
-    """Counter evidence collected offline on this same workload (profiles/collect_pmc.sh -> profiles/r02_pmc_traffic.json:
+    """Counter evidence collected offline on this same workload (profiles/collect_pmc.sh -> profiles/rNN_pmc_traffic.json:
     rocprofv3 kernel trace + separate --pmc FETCH_SIZE / WRITE_SIZE passes, folded per kernel family by
     profiles/pmc_fold.py with the gfx950 correction of MI355X_MICROARCH.md).  Returns the record of this configuration
     (or None) and the name + git commit of the file, so that a stale file is visible in the JSON line."""
-    path = os.path.join(ROOT, 'profiles', 'r02_pmc_traffic.json')
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r[0-9][0-9]_pmc_traffic.json')))      # the newest round's file
     try:
+        path = files[-1]
         rec = json.load(open(path))
         key = '%s_%d_b%d_%s' % (args.arch, args.image_size, args.batch_size, args.dtype)
         cfg = rec['configs'][key]
-        return cfg, {'file': 'profiles/r02_pmc_traffic.json', 'collected_at_commit': cfg.get('git_head'), 'command': cfg.get('command')}
+        return cfg, {'file': 'profiles/' + os.path.basename(path), 'collected_at_commit': cfg.get('git_head'), 'command': cfg.get('command')}
     except Exception:
         return None, None
 
