@@ -782,7 +782,21 @@ class _PwK2CFn(torch.autograd.Function):
 
 
 # ---------------------------------------------------------------- modules
-class Conv2d(nn.Module):
+# Per-forward hand-off slots on the layer modules (plain Python values, rewritten at every forward): nn.Module.__setattr__ walks its
+# parameter / buffer / sub-module bookkeeping for every assignment (~2.5 us each, 1600 of them per iteration: 4 ms of host time, the
+# eager path's margin over the GPU).  These names bypass it.
+_HANDOFF_SLOTS = frozenset(('_last_bias_ctx', '_last_partial', '_in_bn_src', '_last_q8', '_last_src', '_stem_tmp'))
+
+
+class _FastSlots:
+    def __setattr__(self, name, value):
+        if name in _HANDOFF_SLOTS:
+            object.__setattr__(self, name, value)
+        else:
+            super().__setattr__(name, value)
+
+
+class Conv2d(_FastSlots, nn.Module):
     """nn.Conv2d(in, out, k, stride, padding, bias) on the MFMA implicit-GEMM kernels.
     1x1 convs to / from the K-channel heat-maps (K not a multiple of the 16-byte chunk) take the
     dedicated point-wise kernels and exchange NCHW fp32 heat-maps."""
@@ -941,7 +955,7 @@ class Conv2d(nn.Module):
         return _take_partial(self, y), skip
 
 
-class ConvTranspose2d(nn.Module):
+class ConvTranspose2d(_FastSlots, nn.Module):
     """nn.ConvTranspose2d(in, out, 4, stride=2, padding=1, output_padding=0, bias=False)."""
 
     def __init__(self, in_channels, out_channels, kernel_size, stride=2, padding=1, output_padding=0, bias=False):
@@ -1005,7 +1019,7 @@ class ConvTranspose2d(nn.Module):
         return _FUSE_STATS and self.training and self.bn_follows
 
 
-class BatchNorm2d(nn.Module):
+class BatchNorm2d(_FastSlots, nn.Module):
     def __init__(self, num_features, eps=1e-5, momentum=0.1):
         super().__init__()
         self.num_features, self.eps, self.momentum = num_features, eps, momentum
