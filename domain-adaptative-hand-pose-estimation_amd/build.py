@@ -6,7 +6,8 @@ After linking, the device code of the library is disassembled and checked (`isa_
 packed-fp32 arithmetic instruction (v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32) whose LOW result is taken from the high
 register of an operand pair (an `op_sel:[...]` with a 1 in it).  That instruction form lost its swapped operand in lanes
 48-63 of the conv accumulate epilogue now and then on MI355X (round 2; established in round 3 by replacing only that
-instruction in the kernel's assembly: DESIGN.md section 7 "dropped addend", profiles/dropped_addend_repro.py).  The
+instruction in the kernel's assembly -- the src1-swapped form fails, the src0-swapped one did not in that kernel; the gate
+refuses both: DESIGN.md section 7 "dropped addend", profiles/dropped_addend_repro.py).  The
 library is compiled with -fno-slp-vectorize, so hipcc forms no packed fp32 arithmetic from scalar code at all; the gate
 is what keeps it that way when flags or sources change.
 

@@ -11,6 +11,6 @@ $LL/clang -x assembler -target amdgcn-amd-amdhsa -mcpu=gfx950 -c $ASM -o $T/dev.
 $LL/lld -flavor gnu -m elf64_amdgpu --no-undefined -shared -o $T/dev.out $T/dev.o
 $LL/clang-offload-bundler -type=o -bundle-align=4096 -targets=host-x86_64-unknown-linux-gnu,hipv4-amdgcn-amd-amdhsa--gfx950 -input=/dev/null -input=$T/dev.out -output=$T/dev.hipfb
 (cd $SRC && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off --cuda-host-only -Xclang -fcuda-include-gpubinary -Xclang $T/dev.hipfb -c igemm.hip -o $T/igemm.o 2>&1 | grep -v "warning\|^$" || true)
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT $T/igemm.o $B/api.o $B/igemm_fp8.o $B/bn.o $B/pool_layout.o $B/pw21.o $B/heatmap.o $B/optim.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT $T/igemm.o $B/api.o $B/pgemm.o $B/igemm_fp8.o $B/bn.o $B/pool_layout.o $B/pw21.o $B/heatmap.o $B/optim.o
 rm -rf $T
 echo built $OUT
