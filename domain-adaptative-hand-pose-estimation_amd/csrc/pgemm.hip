@@ -89,6 +89,7 @@ __global__ __launch_bounds__(256) void pgemm_kernel(const GatherArgs p) {
   if (total == 0) return;
 
   const __amdgpu_buffer_rsrc_t rsA = make_rsrc(p.A, p.a_bytes), rsB = make_rsrc(p.B, p.b_bytes);
+  (void)rsA; (void)rsB;                                      // (only used in the device pass)
 
   // ---- issue side: tile / K step of the next LDS-DMA stage to launch
   int is_tile = 0, is_kt = 0, is_gs = 0;

@@ -24,8 +24,9 @@ static const char* form_name[NFORMS] = {"pk_add op_sel:[0,1] op_sel_hi:[1,0]", "
                                         "pk_add (default)", "pk_add op_sel_hi:[0,1]", "pk_fma op_sel:[1,0,0]",
                                         "pk_mul op_sel:[1,0]", "pk_add d=src0 op_sel:[0,1] op_sel_hi:[1,0]",
                                         "pk_add d=src1 op_sel:[1,0] op_sel_hi:[0,1]"};
-enum { P_NONE = 0, P_MFMA, P_LDS, P_VMEM, NPARTNERS };
-static const char* partner_name[NPARTNERS] = {"alone", "beside MFMA waves", "beside LDS-read waves", "beside global-load waves"};
+enum { P_NONE = 0, P_MFMA, P_LDS, P_VMEM, P_MFMA_AGPR, NPARTNERS };
+static const char* partner_name[NPARTNERS] = {"alone", "beside MFMA waves", "beside LDS-read waves", "beside global-load waves",
+                                               "beside MFMA waves (AGPR accumulators)"};
 
 template <int FORM>
 __device__ __forceinline__ void probe_body(const float* __restrict__ in, unsigned* __restrict__ bad, int iters, int gtid) {
@@ -107,6 +108,15 @@ __global__ __launch_bounds__(512) void probe(const float* __restrict__ in, float
       acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(y, x, acc, 0, 0, 0);
     }
     sink[blockIdx.x * 512 + t] = acc[0] + acc[7];
+  } else if (PARTNER == P_MFMA_AGPR) {
+    // as in the conv kernel: the partner's accumulators live in the accumulator half of the unified register file
+    f32x16_t acc0 = {0}, acc1 = {0};
+    bf16x8_t x, y;
+    for (int i = 0; i < 8; ++i) { x[i] = (short)(0x3f80 + t + i); y[i] = (short)(0x3f00 + i); }
+    for (int it = 0; it < iters / 2; ++it)
+      asm volatile("v_mfma_f32_32x32x16_bf16 %0, %2, %3, %0\n\tv_mfma_f32_32x32x16_bf16 %1, %3, %2, %1" : "+a"(acc0), "+a"(acc1) : "v"(x), "v"(y));
+    asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");
+    sink[blockIdx.x * 512 + t] = acc0[0] + acc1[7];
   } else if (PARTNER == P_LDS) {
     float4 a = {0, 0, 0, 0};
     for (int it = 0; it < iters; ++it) {
@@ -143,6 +153,7 @@ static void run_form(const float* din, float* dsink, unsigned* dbad, int iters) 
     run<FORM, P_MFMA>(din, dsink, dbad, grids[g], iters);
     run<FORM, P_LDS>(din, dsink, dbad, grids[g], iters);
     run<FORM, P_VMEM>(din, dsink, dbad, grids[g], iters);
+    run<FORM, P_MFMA_AGPR>(din, dsink, dbad, grids[g], iters);
   }
 }
 
