@@ -52,105 +52,121 @@ __global__ __launch_bounds__(256) void pw_c2k_kernel(const T* __restrict__ x, co
 }
 
 // out[n*HW+p][c] = (bias[c] + sum_k y[n][k][p] * w[c][k] + residual) * scale
+// Persistent over the 64-pixel tiles of all images: a block loads the weights of its channel group into LDS once (the K-strided
+// gather of the [C][K] layout costs 42 cache lines per wave load; done per tile it was the larger part of the kernel's time) and
+// then walks tiles blockIdx.x, blockIdx.x + gridDim.x, ...; tile number = n * tiles_per_image + tile_in_image, which is also the
+// statistics slice.
 template <typename T>
 __global__ __launch_bounds__(256) void pw_k2c_kernel(const float* __restrict__ y, const float* __restrict__ w, const float* __restrict__ bias,
                                                       const T* __restrict__ res, const float* __restrict__ scale_dev, T* __restrict__ out,
-                                                      int HW, int C, int K, int wtr, float* __restrict__ stat_partial) {
+                                                      int HW, int C, int K, int wtr, float* __restrict__ stat_partial, int tiles_per_img,
+                                                      int ntiles) {
   constexpr int CH = Chunk<T>::N;
   constexpr int CG = 256 / 8;                               // 32 channel-chunks per block pass, 8 pixel groups
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* ys = reinterpret_cast<float*>(smem);               // [K][PW_PIX]
-  float* ws = ys + K * PW_PIX;                              // [K][CG*CH]  (transposed weights of this channel group)
-  const int n = blockIdx.y, p0 = blockIdx.x * PW_PIX, t = threadIdx.x;
-  const int cbase = blockIdx.z * CG * CH;
-  for (int id = t; id < K * PW_PIX; id += 256) {
-    const int k = id / PW_PIX, p = id % PW_PIX;
-    ys[id] = (p0 + p < HW) ? y[((size_t)n * K + k) * HW + p0 + p] : 0.f;
-  }
+  float* ws = ys + K * PW_PIX;                              // [K][CH/4][CG][4]  (transposed weights of this channel group)
+  float* sp = ws + K * CG * CH;                             // [4 waves][CG*CH][3]   (statistics launches only)
+  const int t = threadIdx.x;
+  const int cbase = blockIdx.y * CG * CH;
+  // weights of this channel group in LDS as [k][CH / 4][CG][4]: a thread's CH channels are CH / 4 float4 reads whose lanes sit
+  // 16 bytes apart (conflict-free)
+  constexpr int NSUB = CH / 4;
   for (int id = t; id < K * CG * CH; id += 256) {
     const int k = id / (CG * CH), c = id % (CG * CH);
-    ws[id] = (cbase + c < C) ? (wtr ? w[(size_t)k * C + cbase + c] : w[(size_t)(cbase + c) * K + k]) : 0.f;
+    const int g = c / CH, e = c % CH;
+    ws[((k * NSUB + (e >> 2)) * CG + g) * 4 + (e & 3)] =
+        (cbase + c < C) ? (wtr ? w[(size_t)k * C + cbase + c] : w[(size_t)(cbase + c) * K + k]) : 0.f;
   }
-  __syncthreads();
   const int cg = t & (CG - 1), pg = t >> 5;                 // pg: 8 pixels each
   const int c0 = cbase + cg * CH;
-  if (c0 >= C && !stat_partial) return;
-  float acc[8][CH];
-#pragma unroll
-  for (int i = 0; i < 8; ++i)
-#pragma unroll
-    for (int e = 0; e < CH; ++e) acc[i][e] = 0.f;
-  for (int k = 0; k < K; ++k) {
-    float wv[CH];
-#pragma unroll
-    for (int e = 0; e < CH; ++e) wv[e] = ws[k * CG * CH + cg * CH + e];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const float yv = ys[k * PW_PIX + pg * 8 + i];
-#pragma unroll
-      for (int e = 0; e < CH; ++e) acc[i][e] = fmaf(yv, wv[e], acc[i][e]);
-    }
-  }
-  const float scale = scale_dev ? *scale_dev : 1.f;
   const bool cok = c0 < C;
+  const float scale = scale_dev ? *scale_dev : 1.f;
   float b[CH];
 #pragma unroll
   for (int e = 0; e < CH; ++e) b[e] = (bias && cok) ? bias[c0 + e] : 0.f;
-  float sn = 0.f, smean[CH], sm2[CH];       // BatchNorm statistics of the stored (rounded) values, as in the gather epilogue
-#pragma unroll
-  for (int e = 0; e < CH; ++e) { smean[e] = 0.f; sm2[e] = 0.f; }
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int p = p0 + pg * 8 + i;
-    if (p >= HW || !cok) continue;
-    const size_t off = ((size_t)n * HW + p) * C + c0;
-    float v[CH];
-#pragma unroll
-    for (int e = 0; e < CH; ++e) v[e] = acc[i][e] + b[e];
-    if (res) { float r[CH]; Chunk<T>::load(res + off, r);
-#pragma unroll
-      for (int e = 0; e < CH; ++e) v[e] += r[e]; }
-#pragma unroll
-    for (int e = 0; e < CH; ++e) v[e] *= scale;
-    Chunk<T>::store(out + off, v);
-    if (stat_partial) {
-      sn += 1.f; const float inv = 1.f / sn;
-#pragma unroll
-      for (int e = 0; e < CH; ++e) { const float q = (float)(T)v[e]; const float d = q - smean[e]; smean[e] += d * inv; sm2[e] += d * (q - smean[e]); }
-    }
-  }
-  if (!stat_partial) return;
-  // fold the 8 pixel groups: lanes 32..63 onto 0..31 inside a wave, then the four waves in order through LDS (fixed order)
-  {
-    const float nb = __shfl_down(sn, 32, 64);
-    const float nt = sn + nb, f = nt > 0.f ? nb / nt : 0.f;
-#pragma unroll
-    for (int e = 0; e < CH; ++e) {
-      const float mb = __shfl_down(smean[e], 32, 64), vb = __shfl_down(sm2[e], 32, 64);
-      const float d = mb - smean[e];
-      smean[e] += d * f; sm2[e] += vb + d * d * sn * f;
-    }
-    sn = nt;
-  }
-  __syncthreads();                                            // ys / ws are dead: reuse the front of the LDS
-  float* sp = reinterpret_cast<float*>(smem);                 // [4 waves][CG*CH][3]
   const int lane = t & 63, wave = t >> 6;
-  if (lane < 32) {
-#pragma unroll
-    for (int e = 0; e < CH; ++e) { float* q = sp + ((size_t)wave * CG * CH + cg * CH + e) * 3; q[0] = sn; q[1] = smean[e]; q[2] = sm2[e]; }
-  }
-  __syncthreads();
-  if (t < CG * CH && cbase + t < C) {
-    float nn = 0.f, mean = 0.f, m2 = 0.f;
-#pragma unroll
-    for (int w2 = 0; w2 < 4; ++w2) {
-      const float* q = sp + ((size_t)w2 * CG * CH + t) * 3;
-      const float nb = q[0];
-      if (nb > 0.f) { const float nt = nn + nb, f = nb / nt, d = q[1] - mean; mean += d * f; m2 += q[2] + d * d * nn * f; nn = nt; }
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int n = tile / tiles_per_img, p0 = (tile - n * tiles_per_img) * PW_PIX;
+    __syncthreads();                                          // the previous tile's reads of ys (and of sp) are done
+    for (int id = t; id < K * PW_PIX; id += 256) {
+      const int k = id / PW_PIX, p = id % PW_PIX;
+      ys[id] = (p0 + p < HW) ? y[((size_t)n * K + k) * HW + p0 + p] : 0.f;
     }
-    const size_t slice = (size_t)n * gridDim.x + blockIdx.x;
-    float* o = stat_partial + (slice * C + cbase + t) * 3;
-    o[0] = nn; o[1] = mean; o[2] = m2;
+    __syncthreads();
+    float sn = 0.f, smean[CH], sm2[CH];       // BatchNorm statistics of the stored (rounded) values, as in the gather epilogue
+#pragma unroll
+    for (int e = 0; e < CH; ++e) { smean[e] = 0.f; sm2[e] = 0.f; }
+    if (cok) {
+      float acc[8][CH];
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int e = 0; e < CH; ++e) acc[i][e] = 0.f;
+      for (int k = 0; k < K; ++k) {
+        float wv[CH];
+#pragma unroll
+        for (int q = 0; q < NSUB; ++q) {
+          const float4 w4 = *reinterpret_cast<const float4*>(ws + ((k * NSUB + q) * CG + cg) * 4);
+          wv[4 * q] = w4.x; wv[4 * q + 1] = w4.y; wv[4 * q + 2] = w4.z; wv[4 * q + 3] = w4.w;
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const float yv = ys[k * PW_PIX + pg * 8 + i];
+#pragma unroll
+          for (int e = 0; e < CH; ++e) acc[i][e] = fmaf(yv, wv[e], acc[i][e]);
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int p = p0 + pg * 8 + i;
+        if (p >= HW) continue;
+        const size_t off = ((size_t)n * HW + p) * C + c0;
+        float v[CH];
+#pragma unroll
+        for (int e = 0; e < CH; ++e) v[e] = acc[i][e] + b[e];
+        if (res) { float r[CH]; Chunk<T>::load(res + off, r);
+#pragma unroll
+          for (int e = 0; e < CH; ++e) v[e] += r[e]; }
+#pragma unroll
+        for (int e = 0; e < CH; ++e) v[e] *= scale;
+        Chunk<T>::store(out + off, v);
+        if (stat_partial) {
+          sn += 1.f; const float inv = 1.f / sn;
+#pragma unroll
+          for (int e = 0; e < CH; ++e) { const float q = (float)(T)v[e]; const float d = q - smean[e]; smean[e] += d * inv; sm2[e] += d * (q - smean[e]); }
+        }
+      }
+    }
+    if (!stat_partial) continue;
+    // fold the 8 pixel groups: lanes 32..63 onto 0..31 inside a wave, then the four waves in order through LDS (fixed order)
+    {
+      const float nb = __shfl_down(sn, 32, 64);
+      const float nt = sn + nb, f = nt > 0.f ? nb / nt : 0.f;
+#pragma unroll
+      for (int e = 0; e < CH; ++e) {
+        const float mb = __shfl_down(smean[e], 32, 64), vb = __shfl_down(sm2[e], 32, 64);
+        const float d = mb - smean[e];
+        smean[e] += d * f; sm2[e] += vb + d * d * sn * f;
+      }
+      sn = nt;
+    }
+    if (lane < 32) {
+#pragma unroll
+      for (int e = 0; e < CH; ++e) { float* q = sp + ((size_t)wave * CG * CH + cg * CH + e) * 3; q[0] = sn; q[1] = smean[e]; q[2] = sm2[e]; }
+    }
+    __syncthreads();
+    if (t < CG * CH && cbase + t < C) {
+      float nn = 0.f, mean = 0.f, m2 = 0.f;
+#pragma unroll
+      for (int w2 = 0; w2 < 4; ++w2) {
+        const float* q = sp + ((size_t)w2 * CG * CH + t) * 3;
+        const float nb = q[0];
+        if (nb > 0.f) { const float nt = nn + nb, f = nb / nt, d = q[1] - mean; mean += d * f; m2 += q[2] + d * d * nn * f; nn = nt; }
+      }
+      float* o = stat_partial + ((size_t)tile * C + cbase + t) * 3;
+      o[0] = nn; o[1] = mean; o[2] = m2;
+    }
   }
 }
 
@@ -254,10 +270,17 @@ extern "C" int mi355_pw_c2k(const void* x, const float* w, const float* bias, fl
 static int pw_k2c_impl(const float* y, const float* w, const float* bias, const void* residual, const float* scale_dev, void* out,
                        int N, int HW, int C, int K, int w_transposed, int dtype, float* stat_partial, void* stream) {
   int CH; if (int e = pw_check(N, HW, C, K, dtype, &CH)) return e;
-  const size_t smem = (size_t)K * PW_PIX * 4 + (size_t)K * 32 * CH * 4;
-  dim3 grid(cdiv(HW, PW_PIX), N, cdiv(C, 32 * CH));
-  if (dtype == MI355_BF16) hipLaunchKernelGGL(pw_k2c_kernel<bf16_t>, grid, dim3(256), smem, as_stream(stream), y, w, bias, (const bf16_t*)residual, scale_dev, (bf16_t*)out, HW, C, K, w_transposed, stat_partial);
-  else hipLaunchKernelGGL(pw_k2c_kernel<float>, grid, dim3(256), smem, as_stream(stream), y, w, bias, (const float*)residual, scale_dev, (float*)out, HW, C, K, w_transposed, stat_partial);
+  const int tiles_per_img = cdiv(HW, PW_PIX), ntiles = N * tiles_per_img;
+  static int ncu = 0;
+  if (!ncu) { hipDeviceProp_t p; int d = 0; (void)hipGetDevice(&d); ncu = (hipGetDeviceProperties(&p, d) == hipSuccess && p.multiProcessorCount > 0) ? p.multiProcessorCount : 256; }
+  static const int per_env = getenv("MI355_PW_PER_CU") ? atoi(getenv("MI355_PW_PER_CU")) : 0;       // experiment switch
+  const size_t smem = (size_t)K * PW_PIX * 4 + (size_t)K * 32 * CH * 4 + (stat_partial ? (size_t)4 * 32 * CH * 3 * 4 : 0);
+  const int cgroups = cdiv(C, 32 * CH);
+  // persistent: four blocks per CU share the tiles (LDS and registers allow 4), fewer when there are fewer tiles
+  int gx = cdiv(ncu * (per_env > 0 ? per_env : 4), cgroups); if (gx > ntiles) gx = ntiles; if (gx < 1) gx = 1;
+  dim3 grid(gx, cgroups);
+  if (dtype == MI355_BF16) hipLaunchKernelGGL(pw_k2c_kernel<bf16_t>, grid, dim3(256), smem, as_stream(stream), y, w, bias, (const bf16_t*)residual, scale_dev, (bf16_t*)out, HW, C, K, w_transposed, stat_partial, tiles_per_img, ntiles);
+  else hipLaunchKernelGGL(pw_k2c_kernel<float>, grid, dim3(256), smem, as_stream(stream), y, w, bias, (const float*)residual, scale_dev, (float*)out, HW, C, K, w_transposed, stat_partial, tiles_per_img, ntiles);
   MI_CHECK_LAUNCH("pw_k2c");
   return MI355_OK;
 }
