@@ -2,7 +2,7 @@
 usage: python profiles/fp8_layer_bench.py [B]"""
 import sys
 import torch
-sys.path[:0] = ['/root/repo', '/root/repo/domain-adaptative-hand-pose-estimation_amd']
+import os; R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path[:0] = [R, R + '/domain-adaptative-hand-pose-estimation_amd']
 import mi355
 from mi355 import ops
 
