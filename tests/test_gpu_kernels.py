@@ -870,6 +870,31 @@ def test_pointwise_k2c_epilogue_bn_statistics(gpu, dt, shape):
     assert float((ya.float() - yb.float()).abs().max()) <= (2e-2 if dt == 'bf16' else 1e-4)
 
 
+def test_pointwise_k2c_walks_several_tiles_per_block_at_full_size(gpu):
+    """The benchmark's 64 x 21 x 64 x 64 heat-maps: 4096 pixel tiles on at most 1024 persistent blocks, so every block walks
+    several tiles with the weights it loaded once.  Output against torch on the same operands, statistics partials against a
+    per-slice torch computation on the stored (rounded) values (slice = 64 consecutive pixels of one image)."""
+    ops = _ops()
+    N, K, C, H, W = 64, 21, 256, 64, 64
+    g = torch.Generator(device='cpu').manual_seed(77)
+    hm = torch.randn(N, K, H, W, generator=g).to(gpu)
+    w = (0.2 * torch.randn(C, K, generator=g)).to(gpu)
+    b = (0.1 * torch.randn(C, generator=g)).to(gpu)
+    res = ops.nhwc_empty(N, C, H, W, torch.bfloat16, gpu).normal_()
+    y0 = ops.pw_k2c(hm, w, b, C, torch.bfloat16, residual=res)
+    y1, part = ops.pw_k2c_stats(hm, w, b, C, torch.bfloat16, residual=res)
+    assert torch.equal(y0, y1) and part[1] == N * (H * W // 64)
+    ref = torch.einsum('nkhw,ck->nchw', hm, w) + b.view(1, -1, 1, 1) + res.float()
+    assert float((y0.float() - ref).abs().max()) <= 2e-2 * float(ref.abs().max())
+    rows = y1.permute(0, 2, 3, 1).reshape(N * H * W // 64, 64, C).float()            # [slice][pixel][channel]
+    p = part[0][:part[1] * C * 3].view(part[1], C, 3)
+    assert torch.equal(p[:, :, 0], torch.full_like(p[:, :, 0], 64.0))
+    mean = rows.mean(dim=1)
+    m2 = ((rows - mean[:, None, :]) ** 2).sum(dim=1)
+    assert float((p[:, :, 1] - mean).abs().max()) <= 1e-5 * float(mean.abs().max() + 1)
+    assert float((p[:, :, 2] - m2).abs().max()) <= 1e-4 * float(m2.abs().max() + 1)
+
+
 def test_grouped_weight_gradients_of_a_resnet_stage_at_full_size(gpu):
     """One wgrad_group launch of layer3's 1x1 convs at the benchmark's size (B=64, 16x16 maps, bf16), every problem against
     torch's fp32 weight gradient on the same bf16-rounded operands (round-2 verdict, item 8)."""
