@@ -158,9 +158,10 @@ extern "C" int mi355_pack_weights_fp8(const float* w_master, void* wf, void* wt,
 }
 
 // ------------------------------------------------------------------------------------ gather GEMM, fp8 operands
-template <int BM, int BN>
+template <int BM, int BN, bool KW3 = false>
 struct Fp8Smem {
-  static constexpr int kStage = (BM + BN) * 128;
+  static constexpr int kARows = KW3 ? BM + 4 * (BM / 8) + 4 : BM;        // KW3: segmented A image with spare rows (as GatherSmem)
+  static constexpr int kStage = (kARows + BN) * 128;
   static constexpr int kOutStride = BN * 2 + 16;             // bf16 output tile rows
   static constexpr int kOut = BM * kOutStride;
   static constexpr int kBytes = (kStage > kOut ? kStage : kOut) + BM * 4;
@@ -169,14 +170,18 @@ struct Fp8Smem {
 // 4 waves (2 x 2), each a (BM/2) x (BN/2) sub-tile of 32x32 MFMA blocks.  K-tile = 128 channels of one tap
 // (8 chunks of 16 bytes); register-staged pipeline over one LDS stage, like the bf16 kernel's default path.
 // A_BF8: the gathered operand is e5m2 (gradients), the weights are always e4m3.  EPI 1: BatchNorm statistics of the output.
-template <int BM, int BN, bool A_BF8, int EPI>
+// KW3: 3x3 / unit-stride layers (forward and input gradient): the three taps of a kernel row read the same pixels shifted by
+// -1 / 0 / +1, so one staged A tile per (kernel row, 128-channel chunk) serves three K sub-steps -- the construction of the bf16
+// kernel's KW3 path (igemm.hip), whose 128-byte rows carry 64 bf16 channels where these carry 128 fp8 channels: same LDS image,
+// same shifted fragment reads.  With the K=64 MFMA these layers are bounded by the tile fills; this takes a third of them away.
+template <int BM, int BN, bool A_BF8, int EPI, bool KW3 = false>
 __global__ __launch_bounds__(256) void gather_fp8_kernel(const GatherArgs p) {
   constexpr int CHI = 16;                                     // fp8 elements per 16-byte chunk
   constexpr int CHO = 8;                                      // bf16 output elements per chunk
   constexpr int NTHR = 256, RPP = 32;
   constexpr int WM = BM / 2, WN = BN / 2, MT = WM / 32, NT = WN / 32;
   constexpr int RA = BM / RPP, RB = BN / RPP;
-  using SM = Fp8Smem<BM, BN>;
+  using SM = Fp8Smem<BM, BN, KW3>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   int* row_off = reinterpret_cast<int*>(smem + SM::kBytes - BM * 4);
 
@@ -230,7 +235,7 @@ __global__ __launch_bounds__(256) void gather_fp8_kernel(const GatherArgs p) {
     }
   };
   char* as = smem;
-  char* bs = smem + BM * 128;
+  char* bs = smem + SM::kARows * 128;
   f32x16_t acc[MT][NT];
 #pragma unroll
   for (int i = 0; i < MT; ++i)
@@ -240,6 +245,81 @@ __global__ __launch_bounds__(256) void gather_fp8_kernel(const GatherArgs p) {
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
   const int r31 = lane & 31, hi = lane >> 5;
 
+  if constexpr (KW3) {
+    // sub-step ks = (group g, kw), group g = (kernel row kh, 128-channel chunk): tap index kh*3 + kw
+    const int nchunk = p.Ci >> 7, nsub = 9 * nchunk;
+    for (int i = t; i < SM::kARows * 8; i += NTHR) reinterpret_cast<uint4*>(as)[i] = make_uint4(0, 0, 0, 0);
+    int simg[RA];                                         // LDS byte offset of this thread's A rows in the segmented image
+#pragma unroll
+    for (int i = 0; i < RA; ++i) { const int r = lr + RPP * i; simg[i] = swz128(r + 2 + 4 * (r >> p.lw), lc); }
+    int rimg[MT];                                         // image row of this lane's fragment rows
+#pragma unroll
+    for (int i = 0; i < MT; ++i) { const int q = wm0 + i * 32 + r31; rimg[i] = q + 2 + 4 * (q >> p.lw); }
+    auto load_a = [&](int g) {
+      const int kh = g / nchunk, chunk = g - kh * nchunk;
+      const int dyv = ptaps[kh * 3].dy;
+      const int toff = dyv * p.Wi * p.Ci + chunk * 128 + lc * CHI;
+#pragma unroll
+      for (int i = 0; i < RA; ++i) {
+        const bool ok = (unsigned)(iy0[i] + dyv) < (unsigned)p.Hi;
+        ra0[i] = buf_load16(rsA, ok ? pix0[i] + toff : OOB_OFF);
+      }
+    };
+    auto load_b = [&](int ks) {
+      const int g = ks / 3, kw = ks - g * 3;
+      const int kh = g / nchunk, chunk = g - kh * nchunk;
+      const int koff = (int)ptaps[kh * 3 + kw].widx * p.Ci + chunk * 128 + lc * CHI;
+#pragma unroll
+      for (int i = 0; i < RB; ++i) {
+        const int n = n0 + lr + RPP * i;
+        rb0[i] = buf_load16(rsB, n < p.Nout ? n * p.ldb + koff : OOB_OFF);
+      }
+    };
+    load_a(0);
+    load_b(0);
+    int kw = 0, g = 0;
+    for (int ks = 0; ks < nsub; ++ks) {
+      const int dxv = ptaps[(g / nchunk) * 3 + kw].dx;
+      __syncthreads();                                    // sub-step ks-1 fully multiplied
+      if (kw == 0) {
+#pragma unroll
+        for (int i = 0; i < RA; ++i) *reinterpret_cast<uint4*>(as + simg[i]) = ra0[i];
+      }
+#pragma unroll
+      for (int i = 0; i < RB; ++i) *reinterpret_cast<uint4*>(bs + swz128(lr + RPP * i, lc)) = rb0[i];
+      __syncthreads();
+      if (ks + 1 < nsub) {
+        load_b(ks + 1);
+        if (kw == 2) load_a(g + 1);                       // the next group's A tile travels during this group's last sub-step
+      }
+      __builtin_amdgcn_s_setprio(1);
+      int arow[MT], axor[MT];
+#pragma unroll
+      for (int i = 0; i < MT; ++i) { const int r = rimg[i] + dxv; arow[i] = r * 128; axor[i] = (r >> 1) & 7; }
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        uint4 a[MT][2], b[NT][2];
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int c = 0; c < 2; ++c) a[i][c] = *reinterpret_cast<const uint4*>(as + arow[i] + (((4 * u + 2 * hi + c) ^ axor[i]) << 4));
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+          for (int c = 0; c < 2; ++c) b[j][c] = *reinterpret_cast<const uint4*>(bs + swz128(wn0 + j * 32 + r31, 4 * u + 2 * hi + c));
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int j = 0; j < NT; ++j) {
+            const i32x8_t av = {(int)a[i][0].x, (int)a[i][0].y, (int)a[i][0].z, (int)a[i][0].w, (int)a[i][1].x, (int)a[i][1].y, (int)a[i][1].z, (int)a[i][1].w};
+            const i32x8_t bv = {(int)b[j][0].x, (int)b[j][0].y, (int)b[j][0].z, (int)b[j][0].w, (int)b[j][1].x, (int)b[j][1].y, (int)b[j][1].z, (int)b[j][1].w};
+            acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(bv, av, acc[i][j], 0, A_BF8 ? 1 : 0, 0, 0, 0, 0);
+          }
+      }
+      __builtin_amdgcn_s_setprio(0);
+      if (++kw == 3) { kw = 0; ++g; }
+    }
+  } else {
   const int nk = (pkchunks + 7) >> 3;
   load_tile(0, ra0, rb0);
   for (int kt = 0; kt < nk; ++kt) {
@@ -278,6 +358,7 @@ __global__ __launch_bounds__(256) void gather_fp8_kernel(const GatherArgs p) {
         }
     }
     __builtin_amdgcn_s_setprio(0);
+  }
   }
   __syncthreads();
 
@@ -372,9 +453,9 @@ __global__ __launch_bounds__(256) void gather_fp8_kernel(const GatherArgs p) {
   }
 }
 
-template <int BM, int BN>
+template <int BM, int BN, bool KW3 = false>
 static void launch_fp8(GatherArgs& a, hipStream_t st) {
-  constexpr int smem = Fp8Smem<BM, BN>::kBytes;
+  constexpr int smem = Fp8Smem<BM, BN, KW3>::kBytes;
   a.ntn = cdiv(a.Nout, BN);
   int mx = 0;
   for (int i = 0; i < a.nphase; ++i) { a.ph[i].ntm = cdiv(a.ph[i].M, BM); if (a.ph[i].ntm > mx) mx = a.ph[i].ntm; }
@@ -386,13 +467,16 @@ static void launch_fp8(GatherArgs& a, hipStream_t st) {
     if (even && (size_t)a.nphase * mx * a.Nout * 3 * sizeof(float) <= a.stat_bytes) a.stat_slices = a.nphase * mx;
     else a.stat_partial = nullptr;
   }
-#define MI_L(BF8, EPI) do { auto kern = gather_fp8_kernel<BM, BN, BF8, EPI>; static bool set_ = false; \
+#define MI_L(BF8, EPI) do { auto kern = gather_fp8_kernel<BM, BN, BF8, EPI, KW3>; static bool set_ = false; \
     if (!set_) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem); set_ = true; } \
     hipLaunchKernelGGL(kern, dim3(a.ntiles), dim3(256), smem, st, a); } while (0)
   if (a.a_fmt) { if (a.stat_partial) MI_L(true, 1); else MI_L(true, 0); }
   else { if (a.stat_partial) MI_L(false, 1); else MI_L(false, 0); }
 #undef MI_L
 }
+
+static long g_fp8_kw3_min = -1;      // run-time switch (mi355_set_fp8_kw3); -1: the environment decides (MI355_FP8_KW3, default 1024)
+extern "C" long mi355_set_fp8_kw3(long min_tiles) { const long prev = g_fp8_kw3_min; g_fp8_kw3_min = min_tiles < 0 ? -1 : min_tiles; return prev; }
 
 static int ilog2x(int v) { int s = 0; while ((1 << s) < v) ++s; return ((1 << s) == v) ? s : -1; }
 
@@ -416,7 +500,23 @@ int dispatch_gather_fp8(GatherArgs& a, hipStream_t st) {
   ProfScope ps(st, flops, (double)abytes + (double)bbytes * ntaps_tot / (a.ldb / a.Ci) + (double)Mtot * a.Nout * 2);
   static const int force = getenv("MI355_FP8_TILE") ? atoi(getenv("MI355_FP8_TILE")) : -1;
   const long t128 = cdiv(Mtot, 128L) * cdiv(a.Nout, 128);
-  if (force == 0 || (force < 0 && t128 >= 512 && a.Nout > 64)) launch_fp8<128, 128>(a, st);
+  // 3x3 / unit stride / same-size maps of a power-of-two width <= 128: the A-tile-sharing variant (KW3 above; conditions as in
+  // dispatch_gather of igemm.hip) from 1024 128x128 tiles on (MI355_FP8_KW3 / mi355_set_fp8_kw3: 0 off, n = smallest tile count).
+  // B=64: 3x3 256->256 @64x64 183 -> 168 us, @32x32 53.5 -> 48.4; below 1024 tiles neutral to slower (@16x16 18.9 -> 21.0).
+  // Iteration: ResNet-101 512x512 76.45 / 76.60 -> 76.24 / 76.05 ms, ResNet-50 32.11 / 32.06 -> 31.92 / 32.04.
+  static const long kw3_env = getenv("MI355_FP8_KW3") ? atol(getenv("MI355_FP8_KW3")) : 1024;
+  const long kw3_min = g_fp8_kw3_min >= 0 ? g_fp8_kw3_min : kw3_env;
+  bool kw3 = kw3_min > 0 && t128 >= kw3_min && a.nphase == 1 && a.ph[0].ntaps == 9 && a.in_sx == 1 && a.in_sy == 1 && a.out_sx == 1 &&
+             a.out_sy == 1 && a.ph[0].OWp == a.Wi && a.ph[0].OHp == a.Hi && a.Wo == a.Wi && a.Ho == a.Hi && a.Wi >= 8 && a.Wi <= 128 &&
+             ilog2x(a.Wi) >= 0 && a.Nout > 64;
+  for (int g = 0; g < 3 && kw3; ++g) {
+    const Tap* tp = a.taps + a.ph[0].tap0 + 3 * g;
+    int seen = 0;
+    for (int k = 0; k < 3; ++k) { if (tp[k].dy != tp[0].dy || tp[k].dx < -1 || tp[k].dx > 1) kw3 = false; else seen |= 1 << (tp[k].dx + 1); }
+    if (seen != 7 || tp[0].dy < -1 || tp[0].dy > 1) kw3 = false;
+  }
+  if (kw3) { a.lw = ilog2x(a.Wi); launch_fp8<128, 128, true>(a, st); }
+  else if (force == 0 || (force < 0 && t128 >= 512 && a.Nout > 64)) launch_fp8<128, 128>(a, st);
   else if (force == 1 || (force < 0 && a.Nout > 64 && cdiv(Mtot, 64L) * cdiv(a.Nout, 128) >= 256)) launch_fp8<64, 128>(a, st);
   else launch_fp8<64, 64>(a, st);
   MI_CHECK_LAUNCH("gather_fp8");

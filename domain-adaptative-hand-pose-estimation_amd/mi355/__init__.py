@@ -78,6 +78,7 @@ SIGNATURES = {
     'mi355_bn_resident_set_spin_limit': (_I, [ctypes.c_uint]),
     'mi355_bn_set_resident': (_I, [_I]),
     'mi355_set_pgemm': (_I, [_I]),
+    'mi355_set_fp8_kw3': (_L, [_L]),
     'mi355_apply_relu_mask': (_I, [_P, _P, _L, _I, _I, _P]),
     'mi355_conv_dgrad_masked_acc': (_I, [_P, _P, _P, _P, _P, _P, _P]),
     'mi355_conv_fwd_act': (_I, [_P, _P, _P, _P, _P, _I, _P, _P]),

@@ -141,6 +141,11 @@ int mi355_conv_fwd_fp8(const mi355_conv_desc* d, const void* x8, int x_fmt, cons
 int mi355_conv_dgrad_fp8(const mi355_conv_desc* d, const void* dy8, int dy_fmt, const void* wT8, const float* descale_dy,
                          const float* descale_w, const float* scale_dev, int accumulate, void* dx, float* partial,
                          size_t partial_bytes, int* nslices, void* stream);
+/* The 3x3 / unit-stride fp8 launches (forward and input gradient) use the variant that stages one operand tile per kernel ROW
+ * and reads it shifted for the three taps (a third fewer bytes per MFMA) from `min_tiles` 128x128 output tiles on: 0 never,
+ * 1 wherever the shape allows (tests), -1 back to the environment's choice (MI355_FP8_KW3, default 1024).  Returns the previous
+ * setting.  Same arithmetic in another summation order (fp32 accumulate). */
+long mi355_set_fp8_kw3(long min_tiles);
 size_t mi355_conv_wgrad_workspace(const mi355_conv_desc* d);
 int mi355_conv_wgrad(const mi355_conv_desc* d, const void* x, const void* dy, float* dw, int accumulate,
                      void* ws, size_t ws_bytes, void* stream);

@@ -109,6 +109,96 @@ def test_conv_fwd_dgrad_fp8_vs_fp32_on_rounded_operands(gpu, case):
         assert err <= 8e-3, 'dgrad %s: %.3e' % (case, err)
 
 
+KW3_CASES = [  # N, H(=W), C(=Ci=Co): every segment geometry of the kernel-row-sharing variant, and non-square channel counts
+    (4, 8, 128, 128), (2, 16, 256, 128), (2, 32, 128, 256), (1, 64, 128, 128), (1, 128, 128, 128), (3, 16, 128, 136)]
+
+
+@pytest.mark.parametrize('case', KW3_CASES)
+def test_fp8_kernel_row_sharing_variant_matches_the_plain_kernel(gpu, case):
+    """3x3 / stride-1 fp8 forward (+bias, statistics) and input gradient (e5m2 operand, lambda, accumulate) through the variant
+    that stages one operand tile per kernel row (forced on through mi355_set_fp8_kw3(1)) against the plain fp8 kernel on the same
+    fp8 operands: the same products in another summation order, so equal up to the bf16 rounding of the result."""
+    ops = _ops()
+    import mi355
+    lib = mi355.load()
+    N, H, Ci, Co = case
+    W = H
+    x = _nhwc(randn(31, N, Ci, H, W).to(gpu).to(torch.bfloat16))
+    w_conv = (randn(32, Co, 3, 3, Ci) / np.sqrt(Ci * 9)).to(gpu)
+    bias = randn(33, Co).to(gpu)
+    sx, sw, sd = ops.fp8_state(gpu), ops.fp8_state(gpu), ops.fp8_state(gpu)
+    x8 = ops.fp8_quantize(x, sx, ops.E4M3, jit=True)
+    Co_p = (Co + 31) // 32 * 32
+    if Co_p != Co:
+        w_conv = torch.cat([w_conv, torch.zeros(Co_p - Co, 3, 3, Ci, device=gpu)], 0)
+    wf8, wt8 = ops.pack_weights_fp8(w_conv, Co_p, 9, Ci, sw)
+    desc = ops.make_desc_fp8(N, H, W, Ci, Co, 3, 3, 1, 1)
+    dy = _nhwc((randn(34, N, Co, H, W) * 1e-3).to(gpu).to(torch.bfloat16))
+    base = _nhwc(randn(35, N, Ci, H, W).to(gpu).to(torch.bfloat16) * 1e-3)
+    lam = torch.full((), 0.25, device=gpu)
+    outs = []
+    prev = lib.mi355_set_fp8_kw3(0)
+    try:
+        for mode in (0, 1):
+            lib.mi355_set_fp8_kw3(mode)
+            y, part = ops.conv_fwd_fp8(desc, x8, sx, wf8, sw, bias, want_stats=True)
+            dx = None
+            if Co % 128 == 0:
+                dy8 = ops.fp8_quantize(dy, sd, ops.E5M2, jit=True)
+                dx = ops.conv_dgrad_fp8(desc, dy8, sd, wt8, sw, scale_dev=lam, out=base.clone(), accumulate=True)
+            torch.cuda.synchronize()
+            outs.append((y, part, dx))
+    finally:
+        lib.mi355_set_fp8_kw3(prev)
+    (y0, p0, dx0), (y1, p1, dx1) = outs
+    scale = float(y0.float().abs().max())
+    assert float((y0.float() - y1.float()).abs().max()) <= 2.0 ** -7 * scale            # one bf16 ulp of the largest value
+    assert float((y0.float() - y1.float()).abs().mean()) <= 2e-4 * scale
+    if p0 is not None and p1 is not None:
+        folded = []                                       # (the two kernels may cut the rows into different slices)
+        for q in (p0, p1):
+            r = q[0][:q[1] * Co * 3].view(q[1], Co, 3).double()
+            n = r[..., 0].sum(0)
+            folded.append((n, (r[..., 0] * r[..., 1]).sum(0) / n))
+        assert torch.equal(folded[0][0], folded[1][0]) and float(folded[0][0].min()) == N * H * W
+        assert float((folded[0][1] - folded[1][1]).abs().max()) <= 1e-4 * scale
+    if dx0 is not None:
+        sd_ = float(dx0.float().abs().max())
+        assert float((dx0.float() - dx1.float()).abs().max()) <= 2.0 ** -7 * sd_
+
+
+def test_fp8_3x3_layer_at_the_benchmarks_size_uses_the_row_sharing_variant(gpu):
+    """64 x 256 x 32 x 32 -> 256, 3x3: 1024 tiles, the size from which the default selects the kernel-row-sharing variant.
+    Against nine shifted fp32 matmuls on the same fp8-rounded operands, and against the plain kernel."""
+    ops = _ops()
+    import mi355
+    lib = mi355.load()
+    N, H, W, C = 64, 32, 32, 256
+    x = ops.nhwc_empty(N, C, H, W, torch.bfloat16, gpu).normal_()
+    w_conv = (randn(42, C, 3, 3, C) / np.sqrt(C * 9)).to(gpu)
+    sx, sw = ops.fp8_state(gpu), ops.fp8_state(gpu)
+    x8 = ops.fp8_quantize(x, sx, ops.E4M3, jit=True)
+    wf8, wt8 = ops.pack_weights_fp8(w_conv, C, 9, C, sw)
+    desc = ops.make_desc_fp8(N, H, W, C, C, 3, 3, 1, 1)
+    y = ops.conv_fwd_fp8(desc, x8, sx, wf8, sw, None)
+    prev = lib.mi355_set_fp8_kw3(0)
+    try:
+        y_plain = ops.conv_fwd_fp8(desc, x8, sx, wf8, sw, None)
+    finally:
+        lib.mi355_set_fp8_kw3(prev)
+    xr = (x8.view(torch.float8_e4m3fn).float() * float(sx[1]))
+    wr = (wf8.view(torch.float8_e4m3fn).float() * float(sw[1])).view(C, 3, 3, C)          # [Co][kh][kw][Ci]
+    xp = F.pad(xr.permute(0, 2, 3, 1), (0, 0, 1, 1, 1, 1))                                   # [N][H+2][W+2][C], zero border
+    ref = torch.zeros(N, H, W, C, device=gpu)
+    for kh in range(3):
+        for kw in range(3):
+            ref += xp[:, kh:kh + H, kw:kw + W, :].reshape(-1, C).matmul(wr[:, kh, kw, :].t()).view(N, H, W, C)
+    ref = ref.permute(0, 3, 1, 2)
+    scale = float(ref.abs().max())
+    assert float((y.float() - ref).abs().max()) <= 6e-3 * scale
+    assert float((y.float() - y_plain.float()).abs().max()) <= 2.0 ** -7 * scale
+
+
 def test_fp8_argument_checks_are_loud(gpu):
     import mi355
     ops = _ops()
