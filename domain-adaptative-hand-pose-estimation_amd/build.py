@@ -25,7 +25,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 OUT = os.path.join(HERE, 'libmi355pose.so')
-SOURCES = ['api.hip', 'igemm.hip', 'pgemm.hip', 'igemm_fp8.hip', 'bn.hip', 'pool_layout.hip', 'pw21.hip', 'heatmap.hip', 'optim.hip']
+SOURCES = ['api.hip', 'igemm.hip', 'pgemm.hip', 'igemm_fp8.hip', 'wgrad_fp8.hip', 'bn.hip', 'pool_layout.hip', 'pw21.hip', 'heatmap.hip', 'optim.hip']
 HEADERS = ['common.h', 'igemm_common.h', 'fp8_common.h']
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 LLVM_BIN = os.environ.get('MI355_LLVM_BIN', '/opt/rocm/lib/llvm/bin')

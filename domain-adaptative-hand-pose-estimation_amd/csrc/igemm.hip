@@ -1107,7 +1107,7 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restric
     }
   }
 }
-static void launch_slab_reduce(const float* ws, float* dw, long n, int S, long stride, int accumulate, hipStream_t st) {
+void launch_slab_reduce(const float* ws, float* dw, long n, int S, long stride, int accumulate, hipStream_t st) {
   const long n4 = n / 4;
   // enough slab lanes that ~64K threads stream, but never more lanes than slabs
   int SL = 1;

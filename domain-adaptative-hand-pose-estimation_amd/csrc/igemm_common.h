@@ -87,3 +87,6 @@ int dispatch_pgemm(GatherArgs& a, hipStream_t st);
 
 // fp8-operand build of the gather GEMM (igemm_fp8.hip).  `a` is filled exactly as for the bf16 kernel (element = byte).
 int dispatch_gather_fp8(GatherArgs& a, hipStream_t st);
+
+// out[i] (+)= sum over S fp32 slabs of n elements, `stride` elements apart (igemm.hip; also used by wgrad_fp8.hip)
+void launch_slab_reduce(const float* ws, float* dw, long n, int S, long stride, int accumulate, hipStream_t st);

@@ -199,6 +199,43 @@ def test_fp8_3x3_layer_at_the_benchmarks_size_uses_the_row_sharing_variant(gpu):
     assert float((y.float() - y_plain.float()).abs().max()) <= 2.0 ** -7 * scale
 
 
+WG8_CASES = [  # N, H, W, Ci, Co, dy format, accumulate
+    (2, 16, 16, 128, 128, 'e5m2', False), (3, 9, 8, 80, 48, 'e5m2', True), (1, 4, 128, 64, 128, 'e5m2', False),
+    (1, 8, 64, 128, 64, 'e4m3', False), (16, 32, 32, 128, 128, 'e5m2', True), (2, 8, 8, 512, 512, 'e5m2', False)]
+
+
+@pytest.mark.parametrize('case', WG8_CASES)
+def test_conv_wgrad_fp8_vs_fp32_on_rounded_operands(gpu, case):
+    """Weight gradient of a 3x3 / stride-1 conv from the fp8 copies of x (e4m3) and dy (e5m2 / e4m3) against nine shifted
+    fp32 matmuls on the same fp8-rounded operands: every segment geometry (W = 8 .. 128, halo rows), ragged pixel and channel
+    counts, direct and slab-reduced launches, accumulation onto an existing gradient."""
+    ops = _ops()
+    N, H, W, Ci, Co, fmt, acc = case
+    x = _nhwc(randn(51, N, Ci, H, W).to(gpu).to(torch.bfloat16))
+    dy = _nhwc((randn(52, N, Co, H, W) * 1e-2).to(gpu).to(torch.bfloat16))
+    sx, sd = ops.fp8_state(gpu), ops.fp8_state(gpu)
+    code = ops.E5M2 if fmt == 'e5m2' else ops.E4M3
+    x8 = ops.fp8_quantize(x, sx, ops.E4M3, jit=True)
+    dy8 = ops.fp8_quantize(dy, sd, code, jit=True)
+    desc = ops.make_desc_fp8(N, H, W, Ci, Co, 3, 3, 1, 1)
+    base = (randn(53, Co, 3, 3, Ci) * 1e-2).to(gpu)
+    dw = base.clone() if acc else torch.full((Co, 3, 3, Ci), float('nan'), device=gpu)
+    ops.conv_wgrad_fp8(desc, x8, sx, dy8, sd, dw, acc, dy_fmt=code)
+    torch.cuda.synchronize()
+    xr = (x8.view(torch.float8_e4m3fn).float() * float(sx[1])).permute(0, 2, 3, 1)              # [N][H][W][Ci]
+    dyr = (dy8.view(torch.float8_e5m2 if fmt == 'e5m2' else torch.float8_e4m3fn).float() * float(sd[1])).permute(0, 2, 3, 1)
+    xp = F.pad(xr, (0, 0, 1, 1, 1, 1))
+    ref = torch.zeros(Co, 3, 3, Ci, device=gpu, dtype=torch.float64)
+    dm = dyr.reshape(-1, Co).double()
+    for kh in range(3):
+        for kw in range(3):
+            ref[:, kh, kw, :] = dm.t().matmul(xp[:, kh:kh + H, kw:kw + W, :].reshape(-1, Ci).double())
+    if acc:
+        ref += base.double()
+    err = float((dw.double() - ref).abs().max()) / float(ref.abs().max())
+    assert err <= 2e-4, 'wgrad_fp8 %s: %.3e' % (case, err)          # exact products, fp32 accumulation (measured: 1 - 4e-5)
+
+
 def test_fp8_argument_checks_are_loud(gpu):
     import mi355
     ops = _ops()
