@@ -399,6 +399,7 @@ def _conv_forward(ctx, mod, x, bias, residual, stats_ok=True):
     if ctx.fp8:
         desc, ctx.desc8, wf8, _, sw = mod._plan_fp8(x)
         x8, sx = mod._q_in.quantize(x)
+        ctx.x8 = (x8, sx) if mod._fp8_wgrad_ok(x) else None      # the weight gradient reads the same e4m3 copy
         y = ops.conv_fwd_fp8(ctx.desc8, x8, sx, wf8, sw, bias, residual, want_stats=want)
         if want:
             y, mod._last_partial = y
@@ -412,6 +413,23 @@ def _conv_forward(ctx, mod, x, bias, residual, stats_ok=True):
     ctx.mod, ctx.desc = mod, desc
     ctx.bn_src = mod._in_bn_src; mod._in_bn_src = None
     return y
+
+
+_FP8_WGRAD = _os.environ.get('MI355_FP8_WGRAD', '1') == '1'      # 0: weight gradients of the fp8 layers on the bf16 kernels (A/B)
+
+
+def _conv_wgrad(ctx, x, dy, weight):
+    """Weight gradient of a conv layer: on the fp8 copies of x (kept from the forward) and dy (made here, reused by the input
+    gradient) for the 3x3 / stride-1 layers of 'fp8' mode, on the bf16 / fp32 kernels otherwise."""
+    mod = ctx.mod
+    x8 = getattr(ctx, 'x8', None)
+    if ctx.fp8 and x8 is not None:
+        dy8, sdy = mod._q_dy.quantize(dy)
+        g, acc = grad_slot(weight)
+        ops.conv_wgrad_fp8(ctx.desc8, x8[0], x8[1], dy8, sdy, g, acc)
+        ctx.x8 = None
+        return
+    mod._wgrad(ctx.desc, x, dy, weight)
 
 
 def _conv_dgrad(ctx, x, dy, scale_dev=None, out=None, accumulate=False, acc_mask=None):
@@ -446,7 +464,7 @@ class _ConvFn(torch.autograd.Function):
         dy = _as_grad(dy, x.dtype)
         dx = None
         if ctx.needs_input_grad[1]:
-            mod._wgrad(desc, x, dy, weight)
+            _conv_wgrad(ctx, x, dy, weight)
         if ctx.needs_input_grad[0]:
             fan = ctx.fan
             onto = fan is not None and fan.buf is not None and fan.buf.shape == x.shape and fan.buf.dtype == x.dtype
@@ -480,7 +498,7 @@ class _ConvSkipFn(torch.autograd.Function):
         mod, desc = ctx.mod, ctx.desc
         dy = _as_grad(dy, x.dtype)
         if ctx.needs_input_grad[1]:
-            mod._wgrad(desc, x, dy, weight)
+            _conv_wgrad(ctx, x, dy, weight)
         dx = None
         if ctx.needs_input_grad[0]:
             if dskip is None:
@@ -865,6 +883,13 @@ class Conv2d(_FastSlots, nn.Module):
             return False
         # a 1x1 conv is HBM-bound: worth it only when its producer already wrote the fp8 copy of x (BatchNorm side output)
         return self.kernel_size[0] >= 3 or _cached_q8(x, ops.E4M3) is not None
+
+    def _fp8_wgrad_ok(self, x):
+        """weight gradient from the fp8 copies too?  The 3x3 / stride-1 / pad-1 layers with a power-of-two width >= 8
+        (mi355_conv_wgrad_fp8); the strided ones and the transposed convs keep the bf16 weight-gradient kernels."""
+        W = x.shape[3]
+        return (_FP8_WGRAD and self.kernel_size[0] == 3 and self.stride[0] == 1 and self.padding[0] == 1 and W >= 8 and
+                (W & (W - 1)) == 0 and self.weight.requires_grad)
 
     def _plan_fp8(self, x):
         N, C, H, W = x.shape

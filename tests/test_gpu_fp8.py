@@ -268,7 +268,8 @@ def fp8_mode():
 def test_fp8_layers_track_the_bf16_layers(gpu, fp8_mode, kind, k, s, p):
     """mi355.nn.Conv2d / ConvTranspose2d in 'fp8' mode against the same layer in 'bf16' mode: forward output and input
     gradient within the e4m3 / e5m2 operand rounding (3 / 2 mantissa bits, errors average over the K = 2304 .. 4096
-    products of one output: relative L2 <= 8e-2), identical weight gradient (the wgrad GEMM stays bf16 on the bf16 copies),
+    products of one output: relative L2 <= 8e-2), weight gradient of the 3x3 / stride-1 layer on the fp8 copies as well (same
+    bound), identical weight gradient for the strided / transposed layers (their wgrad GEMM stays bf16 on the bf16 copies),
     BatchNorm statistics fused in the fp8 epilogue equal to a statistics pass over the fp8 result."""
     from mi355.nn import Conv2d, ConvTranspose2d, BatchNorm2d
     mi355 = fp8_mode
@@ -289,7 +290,11 @@ def test_fp8_layers_track_the_bf16_layers(gpu, fp8_mode, kind, k, s, p):
     e_y, e_dx = _rel(res['fp8'][0], res['bf16'][0]), _rel(res['fp8'][1], res['bf16'][1])
     assert 1e-3 < e_y <= 8e-2, e_y                   # > 1e-3: the fp8 path really ran
     assert 1e-3 < e_dx <= 8e-2, e_dx
-    assert torch.equal(res['fp8'][2], res['bf16'][2])
+    if kind == 'conv' and s == 1:                    # 3x3 / stride 1: the weight gradient runs on the fp8 copies too
+        e_dw = _rel(res['fp8'][2], res['bf16'][2])
+        assert 1e-3 < e_dw <= 8e-2, e_dw
+    else:                                            # strided convs / transposed convs: bf16 weight-gradient kernels
+        assert torch.equal(res['fp8'][2], res['bf16'][2])
     # fused statistics of the fp8 result feed the following BatchNorm
     mi355.set_compute_dtype('fp8')
     bn = BatchNorm2d(256).to(gpu)
