@@ -1,4 +1,4 @@
-"""fp8 vs bf16 gather GEMM on the K-heavy layer shapes (graph-timed in isolation): forward and input gradient.
+"""fp8 vs bf16 conv GEMMs on the K-heavy layer shapes (graph-timed in isolation): forward, input gradient, weight gradient.
 usage: python profiles/fp8_layer_bench.py [B]"""
 import sys
 import torch
@@ -38,10 +38,15 @@ for (H, Ci, Co, k, s, p) in [(64, 256, 256, 3, 1, 1), (64, 256, 256, 3, 2, 1), (
     wf8, wt8 = ops.pack_weights_fp8(w, Co, k * k, Ci, sw)
     x8 = ops.fp8_quantize(x, sx, ops.E4M3, jit=True); dy8 = ops.fp8_quantize(dy, sd, ops.E5M2, jit=True)
     fl = 2.0 * B * d16.Ho * d16.Wo * Co * k * k * Ci
-    for kind in ('fwd', 'dgrad'):
+    kinds = ('fwd', 'dgrad', 'wgrad') if (k == 3 and s == 1) else ('fwd', 'dgrad')
+    dw = torch.zeros(Co * k * k * Ci, device=dev)
+    for kind in kinds:
         if kind == 'fwd':
             t16 = timeit(lambda: ops.conv_fwd(d16, x, wf)); t8 = timeit(lambda: ops.conv_fwd_fp8(d8, x8, sx, wf8, sw))
             tq = timeit(lambda: ops.fp8_quantize(x, sx, ops.E4M3))
+        elif kind == 'wgrad':     # 3x3 / stride 1: weight gradient from the two fp8 copies the other GEMMs already use (no extra pass)
+            t16 = timeit(lambda: ops.conv_wgrad(d16, x, dy, dw, False)); t8 = timeit(lambda: ops.conv_wgrad_fp8(d8, x8, sx, dy8, sd, dw, False))
+            tq = 0.0
         else:
             t16 = timeit(lambda: ops.conv_dgrad(d16, dy, wt)); t8 = timeit(lambda: ops.conv_dgrad_fp8(d8, dy8, sd, wt8, sw))
             tq = timeit(lambda: ops.fp8_quantize(dy, sd, ops.E5M2))
