@@ -61,7 +61,7 @@ SIGNATURES = {
     'mi355_conv_dgrad_fp8': (_I, [_D, _P, _I, _P, _P, _P, _P, _I, _P, _P, _Z, _P, _P]),
     'mi355_conv_wgrad_workspace': (_Z, [_D]),
     'mi355_conv_wgrad_fp8_workspace': (_Z, [_D]),
-    'mi355_conv_wgrad_fp8': (_I, [_D, _P, _P, _I, _P, _P, _P, _I, _P, _Z, _P]),
+    'mi355_conv_wgrad_fp8': (_I, [_D, _P, _I, _P, _I, _P, _P, _P, _I, _P, _Z, _P]),
     'mi355_conv_wgrad': (_I, [_D, _P, _P, _P, _I, _P, _Z, _P]),
     'mi355_conv_wgrad_grouped_workspace': (_Z, [_P, _I]),
     'mi355_conv_wgrad_grouped': (_I, [_P, _I, _P, _Z, _P]),

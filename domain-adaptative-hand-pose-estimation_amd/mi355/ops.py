@@ -296,14 +296,14 @@ def conv_dgrad_fp8(desc, dy8, dy_state, wT8, w_state, scale_dev=None, out=None, 
     return dx
 
 
-def conv_wgrad_fp8(desc, x8, x_state, dy8, dy_state, dw, accumulate, dy_fmt=E5M2, ws_tag='main'):
-    """dw (fp32, [Co][3][3][Ci]) (+)= wgrad(x8, dy8) * descale_x * descale_dy for a 3x3 / stride-1 / pad-1 conv: both operands
-    are the fp8 copies the forward / input-gradient launches of the layer already made."""
+def conv_wgrad_fp8(desc, x8, x_state, dy8, dy_state, dw, accumulate, dy_fmt=E5M2, x_fmt=E4M3, ws_tag='main'):
+    """dw (fp32, [Co][kh][kw][Ci]) (+)= wgrad(x8, dy8) * descale_x * descale_dy for the 3x3 / stride-1 and the 3x3 / 4x4 /
+    stride-2 layers: both operands are the fp8 copies the forward / input-gradient launches of the layer already made."""
     _chk_dev(x8, dy8, dw)
     need = load().mi355_conv_wgrad_fp8_workspace(ctypes.byref(desc))
     ws = workspace(need, x8.device, ws_tag)
-    call('mi355_conv_wgrad_fp8', ctypes.byref(desc), ptr(x8), ptr(dy8), int(dy_fmt), ptr(x_state[1:2]), ptr(dy_state[1:2]),
-         ptr(dw), int(accumulate), ptr(ws), ws.numel(), stream_ptr())
+    call('mi355_conv_wgrad_fp8', ctypes.byref(desc), ptr(x8), int(x_fmt), ptr(dy8), int(dy_fmt), ptr(x_state[1:2]),
+         ptr(dy_state[1:2]), ptr(dw), int(accumulate), ptr(ws), ws.numel(), stream_ptr())
 
 
 # ---------------------------------------------------------------- batch norm

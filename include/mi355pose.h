@@ -146,14 +146,15 @@ int mi355_conv_dgrad_fp8(const mi355_conv_desc* d, const void* dy8, int dy_fmt, 
  * 1 wherever the shape allows (tests), -1 back to the environment's choice (MI355_FP8_KW3, default 1024).  Returns the previous
  * setting.  Same arithmetic in another summation order (fp32 accumulate). */
 long mi355_set_fp8_kw3(long min_tiles);
-/* Weight gradient of a 3x3 / stride-1 / pad-1 conv from the fp8 copies of its operands ('fp8' mode; replaces the bf16
- * mi355_conv_wgrad for the layers of resnet.py:92-107 (Bottleneck conv2), pose_resnet2.py:33-41 and regda_7.py:4906-4929 whose
- * forward and input gradient already run on fp8 operands): dw[Co][3][3][Ci] (fp32) (+)= descale_x * descale_dy *
- * sum_m dy8[m][o] * x8[m + tap][c].  x8: e4m3 [N][H][W][Ci]; dy8: [N][H][W][Co] in e5m2 (dy_fmt 1) or e4m3 (0); `d` an fp8
- * descriptor with a power-of-two width >= 8 and channel counts that are multiples of 16.  Workspace / accumulate as
- * mi355_conv_wgrad. */
+/* Weight gradient of the K-heavy convs from the fp8 copies of their operands ('fp8' mode; replaces the bf16 mi355_conv_wgrad
+ * for the layers of resnet.py:92-107 (Bottleneck conv2, stride 1 and 2), pose_resnet2.py:33-41 (4x4 transposed convs, in
+ * conv-form: x = the output gradient, dy = the input) and regda_7.py:4906-4929 whose forward and input gradient already run on
+ * fp8 operands): dw[Co][kh][kw][Ci] (fp32) (+)= descale_x * descale_dy * sum_m dy8[m][o] * x8[pixel(m, tap)][c].
+ * x8: [N][Hi][Wi][Ci], dy8: [N][Ho][Wo][Co], each e4m3 (format 0) or e5m2 (1); `d` an fp8 descriptor that is either 3x3 /
+ * stride 1 / pad 1 with a power-of-two width >= 8, or 3x3 / 4x4 / stride 2 / pad 1 with even extents and a power-of-two output
+ * width in [8, 64]; channel counts multiples of 16.  Workspace / accumulate as mi355_conv_wgrad. */
 size_t mi355_conv_wgrad_fp8_workspace(const mi355_conv_desc* d);
-int mi355_conv_wgrad_fp8(const mi355_conv_desc* d, const void* x8, const void* dy8, int dy_fmt, const float* descale_x,
+int mi355_conv_wgrad_fp8(const mi355_conv_desc* d, const void* x8, int x_fmt, const void* dy8, int dy_fmt, const float* descale_x,
                          const float* descale_dy, float* dw, int accumulate, void* ws, size_t ws_bytes, void* stream);
 size_t mi355_conv_wgrad_workspace(const mi355_conv_desc* d);
 int mi355_conv_wgrad(const mi355_conv_desc* d, const void* x, const void* dy, float* dw, int accumulate,

@@ -236,6 +236,46 @@ def test_conv_wgrad_fp8_vs_fp32_on_rounded_operands(gpu, case):
     assert err <= 2e-4, 'wgrad_fp8 %s: %.3e' % (case, err)          # exact products, fp32 accumulation (measured: 1 - 4e-5)
 
 
+WG8_S2_CASES = [  # N, H, W (input), Ci, Co, k, x format, dy format, accumulate
+    (2, 16, 16, 128, 128, 3, 'e4m3', 'e5m2', False), (3, 18, 16, 80, 48, 3, 'e4m3', 'e5m2', True),
+    (2, 32, 32, 128, 256, 4, 'e5m2', 'e4m3', False), (1, 128, 128, 64, 64, 4, 'e5m2', 'e4m3', False),
+    (16, 32, 32, 256, 128, 3, 'e4m3', 'e4m3', True), (2, 16, 16, 512, 512, 4, 'e5m2', 'e4m3', False)]
+
+
+@pytest.mark.parametrize('case', WG8_S2_CASES)
+def test_conv_wgrad_fp8_stride2_vs_fp64_on_rounded_operands(gpu, case):
+    """Weight gradient of the 3x3 / 4x4 stride-2 pad-1 layers (and, with the roles the conv-form of a 4x4 transposed conv gives
+    its operands: x in e5m2, dy in e4m3) from the fp8 copies, against k*k strided fp64 matmuls on the same fp8-rounded operands:
+    output widths 8 .. 64, ragged channel counts and pixel counts, direct and slab-reduced launches, accumulation."""
+    ops = _ops()
+    N, H, W, Ci, Co, k, fx, fy, acc = case
+    Ho, Wo = H // 2, W // 2
+    f8 = {'e4m3': (ops.E4M3, torch.float8_e4m3fn), 'e5m2': (ops.E5M2, torch.float8_e5m2)}
+    x = _nhwc(randn(61, N, Ci, H, W).to(gpu).to(torch.bfloat16))
+    dy = _nhwc((randn(62, N, Co, Ho, Wo) * 1e-2).to(gpu).to(torch.bfloat16))
+    sx, sd = ops.fp8_state(gpu), ops.fp8_state(gpu)
+    x8 = ops.fp8_quantize(x, sx, f8[fx][0], jit=True)
+    dy8 = ops.fp8_quantize(dy, sd, f8[fy][0], jit=True)
+    desc = ops.make_desc_fp8(N, H, W, Ci, Co, k, k, 2, 1)
+    base = (randn(63, Co, k, k, Ci) * 1e-2).to(gpu)
+    dw = base.clone() if acc else torch.full((Co, k, k, Ci), float('nan'), device=gpu)
+    ops.conv_wgrad_fp8(desc, x8, sx, dy8, sd, dw, acc, dy_fmt=f8[fy][0], x_fmt=f8[fx][0])
+    torch.cuda.synchronize()
+    xr = (x8.view(f8[fx][1]).float() * float(sx[1])).permute(0, 2, 3, 1)
+    dyr = (dy8.view(f8[fy][1]).float() * float(sd[1])).permute(0, 2, 3, 1)
+    xp = F.pad(xr, (0, 0, 1, 2, 1, 2))                                                          # pad 1 (+1 spare for the 4x4 taps)
+    ref = torch.zeros(Co, k, k, Ci, device=gpu, dtype=torch.float64)
+    dm = dyr.reshape(-1, Co).double()
+    for kh in range(k):
+        for kw in range(k):
+            patch = xp[:, kh:kh + 2 * Ho:2, kw:kw + 2 * Wo:2, :]                                  # input pixel 2*o + tap - 1
+            ref[:, kh, kw, :] = dm.t().matmul(patch.reshape(-1, Ci).double())
+    if acc:
+        ref += base.double()
+    err = float((dw.double() - ref).abs().max()) / float(ref.abs().max())
+    assert err <= 2e-4, 'wgrad_fp8 s2 %s: %.3e' % (case, err)
+
+
 def test_fp8_argument_checks_are_loud(gpu):
     import mi355
     ops = _ops()
