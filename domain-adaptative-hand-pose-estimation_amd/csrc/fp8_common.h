@@ -2,7 +2,11 @@
 #pragma once
 #include "common.h"
 
-// state[0] = scale (x_q = x * scale), state[1] = descale = 1 / scale, state[2] = amax seen since the last update (bits)
+// state[0] = scale (x_q = x * scale), state[1] = descale = 1 / scale, state[2] = amax seen since the last update (bits),
+// state[3] = the descale of the COPY most recently made with this record (weight packs: the packed copy outlives the scale
+// refresh that follows its optimizer step, so its consumers read [3], not [1]).  Activation copies carry their own 16-byte
+// record {scale, descale, 0, 0} behind their data instead (mi355_fp8_quantize, write = 2): several copies of one stream are
+// alive at once (a forward shared by two backward passes with an optimizer step -- and its scale refresh -- in between).
 __device__ __forceinline__ float clamp_fp8(float v, float lim) {   // saturate; NaN stays NaN
   return v != v ? v : fminf(fmaxf(v, -lim), lim);
 }

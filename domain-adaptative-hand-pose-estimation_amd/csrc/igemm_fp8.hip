@@ -19,9 +19,11 @@ typedef int i32x8_t __attribute__((ext_vector_type(8)));
 // 16 input elements per thread-iteration -> one 16-byte fp8 chunk.  amax over |x| (before scaling) into state[2] via an
 // integer atomic max on the float bits (exact and order-independent).
 template <typename T, bool BF8, bool WRITE>
-__global__ __launch_bounds__(256) void quantize_fp8_kernel(const T* __restrict__ x, unsigned char* __restrict__ q, float* __restrict__ state, long n16) {
+__global__ __launch_bounds__(256) void quantize_fp8_kernel(const T* __restrict__ x, unsigned char* __restrict__ q, float* __restrict__ state, long n16,
+                                                            float* __restrict__ rec) {
   constexpr int PER = Chunk<T>::N, NC = 16 / PER;
   const float scale = state[0];
+  if (WRITE && rec && blockIdx.x == 0 && threadIdx.x == 0) { rec[0] = scale; rec[1] = state[1]; rec[2] = 0.f; rec[3] = 0.f; }   // this copy's own record
   const unsigned seen = fp8_amax_seen(state);
   float amax = 0.f;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (long)gridDim.x * blockDim.x) {
@@ -64,12 +66,14 @@ __global__ void fp8_update_scale_kernel(float* __restrict__ states, int n, int s
 extern "C" int mi355_fp8_quantize(const void* x, void* q, float* state, long n, int src_dtype, int fmt, int write, void* stream) {
   if (!x || !state || (write && !q) || n < 16 || n % 16) MI_FAIL(MI355_EINVAL, "fp8_quantize: n=%ld must be a positive multiple of 16", n);
   if (fmt != 0 && fmt != 1) MI_FAIL(MI355_EINVAL, "fp8_quantize: fmt %d (0 = e4m3, 1 = e5m2)", fmt);
+  if (write < 0 || write > 2) MI_FAIL(MI355_EINVAL, "fp8_quantize: write %d (0 = amax only, 1 = copy, 2 = copy + its 16-byte scale record)", write);
   if (src_dtype != MI355_BF16 && src_dtype != MI355_F32) MI_FAIL(MI355_EINVAL, "fp8_quantize: source dtype %d", src_dtype);
   const long n16 = n / 16;
   int grid = (int)((n16 + 255) / 256); if (grid > 1024) grid = 1024;
   hipStream_t st = as_stream(stream);
   unsigned char* o = reinterpret_cast<unsigned char*>(q);
-#define MI_Q(T, BF8, W) hipLaunchKernelGGL((quantize_fp8_kernel<T, BF8, W>), dim3(grid), dim3(256), 0, st, (const T*)x, o, state, n16)
+  float* rec = write == 2 ? reinterpret_cast<float*>(o + n) : nullptr;      // write = 2: q has 16 more bytes, the copy's {scale, descale, 0, 0}
+#define MI_Q(T, BF8, W) hipLaunchKernelGGL((quantize_fp8_kernel<T, BF8, W>), dim3(grid), dim3(256), 0, st, (const T*)x, o, state, n16, rec)
   if (src_dtype == MI355_BF16) {
     if (!write) MI_Q(bf16_t, false, false); else if (fmt) MI_Q(bf16_t, true, true); else MI_Q(bf16_t, false, true);
   } else {
@@ -97,6 +101,7 @@ __device__ __forceinline__ void pack_fp8_block(const float* __restrict__ w, unsi
   __shared__ float red[4];
   const float scale = state[0];
   const unsigned seen = fp8_amax_seen(state);
+  if (b == 0 && threadIdx.x == 0) state[3] = state[1];      // the descale that belongs to THIS packed copy (fp8_common.h)
   const int tiles_i = I / 32, tiles_o = O / 32;
   const int tap = b / (tiles_i * tiles_o), r = b % (tiles_i * tiles_o);
   const int o0 = (r / tiles_i) * 32, i0 = (r % tiles_i) * 32;

@@ -231,7 +231,8 @@ def fp8_update_scale(states, n=1, fmt=E4M3, margin=None):
 def fp8_quantize(x, state, fmt=E4M3, jit=False):
     """bf16 / fp32 device tensor (any dense layout) -> uint8 tensor of the same shape and strides holding
     saturate_fmt(x * state[0]).  jit=True: first take amax(|x|) and derive the scale from it (one extra read of x);
-    otherwise the scale already in `state` is used and the amax of x is recorded for the next update (delayed scaling)."""
+    otherwise the scale already in `state` is used and the amax of x is recorded for the next update (delayed scaling).
+    The returned tensor's `_mi_rec` is a 4-float record {scale, descale, 0, 0} of THIS copy, usable wherever a state is."""
     _chk_dev(x, state)
     if not (x.is_contiguous() or x.is_contiguous(memory_format=torch.channels_last)):
         raise Mi355Error('fp8_quantize needs a dense tensor')
@@ -240,8 +241,13 @@ def fp8_quantize(x, state, fmt=E4M3, jit=False):
     if jit:
         fp8_amax(x, state)
         fp8_update_scale(state, 1, fmt)
-    q = torch.empty_like(x, dtype=torch.uint8)
-    call('mi355_fp8_quantize', ptr(x), ptr(q), ptr(state), x.numel(), dtype_code(x.dtype), int(fmt), 1, stream_ptr())
+    # the copy carries its own {scale, descale, 0, 0} record in 16 bytes behind the data (q._mi_rec): the stream's state is
+    # refreshed at every optimizer step, a copy may be consumed after that (weight gradient of a forward shared by two backwards)
+    n = x.numel()
+    full = torch.empty(n + 16, dtype=torch.uint8, device=x.device)
+    q = full.as_strided(x.shape, x.stride())
+    call('mi355_fp8_quantize', ptr(x), ptr(full), ptr(state), n, dtype_code(x.dtype), int(fmt), 2, stream_ptr())
+    q._mi_rec = full[n:].view(torch.float32)
     return q
 
 

@@ -304,14 +304,17 @@ def fp8_mode():
     mi355.set_compute_dtype('bf16')
 
 
+@pytest.mark.parametrize('wgrad8', [False, True])
 @pytest.mark.parametrize('kind,k,s,p', [('conv', 3, 1, 1), ('conv', 3, 2, 1), ('deconv', 4, 2, 1)])
-def test_fp8_layers_track_the_bf16_layers(gpu, fp8_mode, kind, k, s, p):
+def test_fp8_layers_track_the_bf16_layers(gpu, fp8_mode, kind, k, s, p, wgrad8, monkeypatch):
     """mi355.nn.Conv2d / ConvTranspose2d in 'fp8' mode against the same layer in 'bf16' mode: forward output and input
     gradient within the e4m3 / e5m2 operand rounding (3 / 2 mantissa bits, errors average over the K = 2304 .. 4096
-    products of one output: relative L2 <= 8e-2), weight gradient of the 3x3 / stride-1 layer on the fp8 copies as well (same
-    bound), identical weight gradient for the strided / transposed layers (their wgrad GEMM stays bf16 on the bf16 copies),
+    products of one output: relative L2 <= 8e-2), identical weight gradient by default (the wgrad GEMM stays bf16), within the
+    same bound with the opt-in fp8 weight gradients,
     BatchNorm statistics fused in the fp8 epilogue equal to a statistics pass over the fp8 result."""
     from mi355.nn import Conv2d, ConvTranspose2d, BatchNorm2d
+    import mi355.nn as mnn
+    monkeypatch.setattr(mnn, '_FP8_WGRAD', wgrad8)           # (opt-in switch MI355_FP8_WGRAD)
     mi355 = fp8_mode
     torch.manual_seed(0)
     mod = (Conv2d(256, 256, k, s, p, bias=(s == 1)) if kind == 'conv' else ConvTranspose2d(256, 256, k, s, p)).to(gpu)
@@ -330,10 +333,10 @@ def test_fp8_layers_track_the_bf16_layers(gpu, fp8_mode, kind, k, s, p):
     e_y, e_dx = _rel(res['fp8'][0], res['bf16'][0]), _rel(res['fp8'][1], res['bf16'][1])
     assert 1e-3 < e_y <= 8e-2, e_y                   # > 1e-3: the fp8 path really ran
     assert 1e-3 < e_dx <= 8e-2, e_dx
-    if kind == 'conv' and s == 1:                    # 3x3 / stride 1: the weight gradient runs on the fp8 copies too
+    if wgrad8:                                       # opt-in: the weight gradient runs on the fp8 copies too (all three kinds)
         e_dw = _rel(res['fp8'][2], res['bf16'][2])
         assert 1e-3 < e_dw <= 8e-2, e_dw
-    else:                                            # strided convs / transposed convs: bf16 weight-gradient kernels
+    else:                                            # default: the wgrad GEMM stays bf16 on the bf16 operands
         assert torch.equal(res['fp8'][2], res['bf16'][2])
     # fused statistics of the fp8 result feed the following BatchNorm
     mi355.set_compute_dtype('fp8')
@@ -394,9 +397,13 @@ def test_fp8_resnet101_forward_and_resnet50_iteration_vs_reference(gpu, fp8_mode
             assert torch.isfinite(p).all() and (inert or not torch.equal(p, before[k])), k
 
 
-def test_fp8_training_reduces_the_supervised_loss(gpu, fp8_mode):
+@pytest.mark.parametrize('wgrad8', [False, True])
+def test_fp8_training_reduces_the_supervised_loss(gpu, fp8_mode, wgrad8, monkeypatch):
     """80 A/B/C iterations on one fixed synthetic batch (ResNet-18, 128x128, B=4) in 'fp8' mode: delayed scaling keeps every
-    operand in range (finite losses) and the supervised loss falls by more than a third, as in bf16 mode."""
+    operand in range (finite losses) and the supervised loss falls by more than a third, as in bf16 mode -- also with the
+    opt-in fp8 weight gradients (ResNet-18's BasicBlocks: stride-1 and stride-2 3x3 layers, the three 4x4 transposed convs)."""
+    import mi355.nn as mnn
+    monkeypatch.setattr(mnn, '_FP8_WGRAD', wgrad8)
     import uda.model as models
     from mi355.da_step import build_training
     from uda.model.pose_resnet2 import Upsampling
