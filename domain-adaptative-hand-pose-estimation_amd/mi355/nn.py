@@ -396,9 +396,11 @@ def _bias_grad(ctx, bias, dy):
 def _conv_forward(ctx, mod, x, bias, residual, stats_ok=True):
     """conv forward on the bf16 / fp32 kernels or, in 'fp8' mode, on fp8 operands; leaves the plan on ctx."""
     want = stats_ok and mod._want_stats() and residual is None
-    ctx.fp8 = mod._fp8_ok(x)
-    if ctx.fp8:
+    ok8 = mod._fp8_ok(x)
+    ctx.fp8 = ok8 and 'd' in _FP8_PARTS                          # (input gradient on fp8 operands)
+    if ok8:
         desc, ctx.desc8, wf8, _, sw = mod._plan_fp8(x)
+    if ok8 and 'f' in _FP8_PARTS:
         x8, sx = mod._q_in.quantize(x)
         ctx.x8 = (x8, sx) if mod._fp8_wgrad_ok(x) else None      # the weight gradient reads the same e4m3 copy
         y = ops.conv_fwd_fp8(ctx.desc8, x8, sx, wf8, sw, bias, residual, want_stats=want)
@@ -420,6 +422,12 @@ def _conv_forward(ctx, mod, x, bias, residual, stats_ok=True):
 # per iteration, but on the synthetic fixed-batch run the supervised loss after 300 / 600 iterations is 29.1 / 24.0 against
 # 22.1 / 19.0 with bf16 weight gradients (and 20.6 / 7.0 in bf16 mode): the e5m2 gradient operand costs more than it buys.
 _FP8_WGRAD = _os.environ.get('MI355_FP8_WGRAD', '0') == '1'
+_FP8_PARTS = _os.environ.get('MI355_FP8_PARTS', 'fd')      # experiment: which GEMMs of the fp8 convs take fp8 operands (f forward, d input gradient)
+# 'fp8' mode: the 4x4 transposed convs of the neck on fp8 operands too.  OPT-IN: they are worth 0.2 ms of a 32.4 ms iteration
+# (0.6 of 77 at 512x512) and cost most of what 'fp8' mode loses in convergence on the synthetic fixed-batch run (supervised loss
+# after 600 iterations: 7.0 in bf16 mode, 10.4 with fp8 convs only, 18.9 with fp8 transposed convs only, 19.0 with both)
+_FP8_DECONV = _os.environ.get('MI355_FP8_DECONV', '0') == '1'
+_GRAD_FMT = ops.E4M3 if _os.environ.get('MI355_FP8_GRAD_FMT', 'e5m2') == 'e4m3' else ops.E5M2      # experiment: gradient operand format
 _FP8_WGRAD_SKIP = _os.environ.get('MI355_FP8_WGRAD_SKIP', '').split(',')      # experiment: 's1', 's2', 'dc' keep their bf16 kernels
 
 
@@ -431,7 +439,7 @@ def _conv_wgrad(ctx, x, dy, weight):
     if ctx.fp8 and x8 is not None:
         dy8, sdy = mod._q_dy.quantize(dy)
         g, acc = grad_slot(weight)
-        ops.conv_wgrad_fp8(ctx.desc8, x8[0], x8[1], dy8, sdy, g, acc)
+        ops.conv_wgrad_fp8(ctx.desc8, x8[0], x8[1], dy8, sdy, g, acc, dy_fmt=_GRAD_FMT)
         ctx.x8 = None
         return
     mod._wgrad(ctx.desc, x, dy, weight)
@@ -448,7 +456,7 @@ def _conv_dgrad(ctx, x, dy, scale_dev=None, out=None, accumulate=False, acc_mask
     if ctx.fp8:
         _, _, _, wt8, sw = mod._plan_fp8(x)
         dy8, sdy = mod._q_dy.quantize(dy)
-        return ops.conv_dgrad_fp8(ctx.desc8, dy8, sdy, wt8, sw, scale_dev=scale_dev, out=out, accumulate=accumulate)
+        return ops.conv_dgrad_fp8(ctx.desc8, dy8, sdy, wt8, sw, scale_dev=scale_dev, out=out, accumulate=accumulate, dy_fmt=_GRAD_FMT)
     _, _, wt = mod._plan(x)
     return _dgrad_for_bn(ctx.desc, dy, wt, ctx.bn_src, x, scale_dev=scale_dev, out=out, accumulate=accumulate)
 
@@ -553,7 +561,7 @@ class _DeconvFn(torch.autograd.Function):
             # output gradient is this layer's input (the e4m3 copy of the forward)
             g, acc = grad_slot(weight)
             dy8, sdy = mod._q_dy.quantize(dy)
-            ops.conv_wgrad_fp8(ctx.desc8, dy8, sdy, x8[0], x8[1], g, acc, dy_fmt=ops.E4M3, x_fmt=ops.E5M2)
+            ops.conv_wgrad_fp8(ctx.desc8, dy8, sdy, x8[0], x8[1], g, acc, dy_fmt=ops.E4M3, x_fmt=_GRAD_FMT)
             ctx.x8 = None
         elif ctx.needs_input_grad[1]:
             g, acc = grad_slot(weight)
@@ -569,7 +577,7 @@ class _DeconvFn(torch.autograd.Function):
         if ctx.needs_input_grad[0] and ctx.fp8:
             _, _, wf8, _, sw = mod._plan_fp8(x)
             dy8, sdy = mod._q_dy.quantize(dy)
-            dx = ops.conv_fwd_fp8(ctx.desc8, dy8, sdy, wf8, sw, x_fmt=ops.E5M2)
+            dx = ops.conv_fwd_fp8(ctx.desc8, dy8, sdy, wf8, sw, x_fmt=_GRAD_FMT)
         elif ctx.needs_input_grad[0]:
             _, wf, _ = mod._plan(x)
             if ctx.bn_src is None:
@@ -841,7 +849,7 @@ class Conv2d(_FastSlots, nn.Module):
         self.weight = _convform_param(out_channels, in_channels, k, k)
         self.bias = nn.Parameter(torch.empty(out_channels)) if bias else None
         self._packed = _PackedWeights()
-        self._packed8, self._q_in, self._q_dy = _PackedFp8(), _Fp8Stream(ops.E4M3), _Fp8Stream(ops.E5M2)
+        self._packed8, self._q_in, self._q_dy = _PackedFp8(), _Fp8Stream(ops.E4M3), _Fp8Stream(_GRAD_FMT)
         self._cast = _CastCopy()
         self._cast_t = _CastCopy(transposed=True)
         self._folded = _FoldedBn()
@@ -1014,14 +1022,15 @@ class ConvTranspose2d(_FastSlots, nn.Module):
         self.bias = None
         self._packed = _PackedWeights()
         self._folded = _FoldedBn()
-        self._packed8, self._q_in, self._q_dy = _PackedFp8(), _Fp8Stream(ops.E4M3), _Fp8Stream(ops.E5M2)
+        self._packed8, self._q_in, self._q_dy = _PackedFp8(), _Fp8Stream(ops.E4M3), _Fp8Stream(_GRAD_FMT)
         self._last_partial = None
         self._in_bn_src = None
         self.bn_follows = False
         nn.init.kaiming_uniform_(self.weight, a=math.sqrt(5))
 
     def _fp8_ok(self, x):
-        return (_rt.fp8_convs() and x.dtype == torch.bfloat16 and self.in_channels % 128 == 0 and self.out_channels % 128 == 0)
+        return (_FP8_DECONV and _rt.fp8_convs() and x.dtype == torch.bfloat16 and self.in_channels % 128 == 0 and
+                self.out_channels % 128 == 0)
 
     def _fp8_wgrad_ok(self, x):
         """weight gradient from the fp8 copies too?  The 4x4 / stride-2 / pad-1 layers whose input width (the conv-form's

@@ -315,6 +315,7 @@ def test_fp8_layers_track_the_bf16_layers(gpu, fp8_mode, kind, k, s, p, wgrad8, 
     from mi355.nn import Conv2d, ConvTranspose2d, BatchNorm2d
     import mi355.nn as mnn
     monkeypatch.setattr(mnn, '_FP8_WGRAD', wgrad8)           # (opt-in switch MI355_FP8_WGRAD)
+    monkeypatch.setattr(mnn, '_FP8_DECONV', True)            # (opt-in switch MI355_FP8_DECONV: transposed convs on fp8 operands)
     mi355 = fp8_mode
     torch.manual_seed(0)
     mod = (Conv2d(256, 256, k, s, p, bias=(s == 1)) if kind == 'conv' else ConvTranspose2d(256, 256, k, s, p)).to(gpu)
@@ -404,6 +405,7 @@ def test_fp8_training_reduces_the_supervised_loss(gpu, fp8_mode, wgrad8, monkeyp
     opt-in fp8 weight gradients (ResNet-18's BasicBlocks: stride-1 and stride-2 3x3 layers, the three 4x4 transposed convs)."""
     import mi355.nn as mnn
     monkeypatch.setattr(mnn, '_FP8_WGRAD', wgrad8)
+    monkeypatch.setattr(mnn, '_FP8_DECONV', wgrad8)         # the opt-in run exercises the fp8 transposed convs as well
     import uda.model as models
     from mi355.da_step import build_training
     from uda.model.pose_resnet2 import Upsampling
