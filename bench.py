@@ -294,7 +294,11 @@ def main():
                                    'adversarial multiscale-fusion heads, %dx%d, batch %d source + %d target per GPU, '
                                    'random init, synthetic batches' % (args.arch, S, S, B, B),
                        'arch': args.arch, 'image_size': S, 'per_gpu_batch': B, 'global_batch': B * world,
-                       'parallelism': 'dp%d' % world, 'hip_graphs': use_graph},
+                       'parallelism': 'dp%d' % world, 'hip_graphs': use_graph,
+                       **({'fp8_gemms': 'forward + input gradient of the 3x3 convs'
+                           + (', transposed convs' if os.environ.get('MI355_FP8_DECONV', '0') == '1' else '')
+                           + (', weight gradients' if os.environ.get('MI355_FP8_WGRAD', '0') == '1' else '')}
+                          if args.dtype == 'fp8' else {})},
             'model_passes_per_s': round(3 * B * world / (ms_per_step * 1e-3), 2),
             'eval_images_per_s_per_gpu': round(B / (eval_ms * 1e-3), 1) if eval_ms else None,
             'losses_last_step': losses,
