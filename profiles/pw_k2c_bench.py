@@ -1,46 +1,28 @@
-"""Heat-map -> feature 1x1 conv (K=21 -> C=256; the input gradient of the heads' last conv and the forward of `heatmap_conv`):
-the fp32 VALU kernel against the same product on the MFMA gather kernel (heat-maps re-laid as NHWC bf16 with K padded to 32).
-usage: python profiles/pw_k2c_bench.py"""
-import sys
-import torch
-sys.path[:0] = ['/root/repo', '/root/repo/domain-adaptative-hand-pose-estimation_amd']
+"""pw_k2c (21 -> 256 channels) in isolation: plain, + residual, + residual + statistics; md5 of the output for bit-identity checks
+across builds (MI355_LIB=...).  python profiles/pw_k2c_bench.py [tag]"""
+import os, sys, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, 'domain-adaptative-hand-pose-estimation_amd'), os.path.join(ROOT, 'profiles')]
 import mi355
 from mi355 import ops
-
-dev = torch.device('cuda:0'); mi355.load(); dt = torch.bfloat16
-
-
-def timeit(fn, n=30):
-    for _ in range(3):
-        fn()
-    g = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(g):
-        for _ in range(n):
-            fn()
-    g.replay(); torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(True), torch.cuda.Event(True)
-    e0.record(); g.replay(); e1.record(); torch.cuda.synchronize()
-    return e0.elapsed_time(e1) / n * 1e3
-
-
-for S in (64, 32, 16):
-    N, K, C = 64, 21, 256
-    hm = torch.randn(N, K, S, S, device=dev)
+from pgemm_bench import timeit
+mi355.load()
+dev = torch.device("cuda:0"); torch.manual_seed(3)
+tag = sys.argv[1] if len(sys.argv) > 1 else ''
+for (N, H, C, K) in [(64, 64, 256, 21), (64, 32, 256, 21), (64, 64, 256, 42)]:
+    if K > 32: continue
+    y = torch.randn(N, K, H, H, device=dev)
     w = torch.randn(C, K, device=dev) * 0.1
-    res = ops.nhwc_empty(N, C, S, S, dt, dev).normal_()
-    t0 = timeit(lambda: ops.pw_k2c(hm, w, None, C, dt))
-    t1 = timeit(lambda: ops.pw_k2c(hm, w, None, C, dt, residual=res))
-    t2 = timeit(lambda: ops.pw_k2c_stats(hm, w, None, C, dt, residual=res))
-    wp = torch.zeros(C, 32, device=dev); wp[:, :K] = w
-    wf = wp.to(dt).contiguous().view(-1)
-    desc = ops.make_desc(N, S, S, 32, C, 1, 1, 1, 0, dt)
-    t3 = timeit(lambda: ops.to_nhwc(hm, dt, 32))
-    h32 = ops.to_nhwc(hm, dt, 32)
-    t4 = timeit(lambda: ops.conv_fwd(desc, h32, wf))
-    t5 = timeit(lambda: ops.conv_fwd(desc, h32, wf, residual=res))
-    t6 = timeit(lambda: ops.conv_fwd_stats(desc, h32, wf))
-    a = ops.pw_k2c(hm, w, None, C, dt).float(); b = ops.conv_fwd(desc, h32, wf).float()
-    err = float((a - b).norm() / a.norm())
-    mb = N * S * S * C * 2 / 1e6
-    print('%dx%d: VALU %.1f us (+residual %.1f, +stats %.1f) | relayout %.1f + MFMA %.1f (+residual %.1f, stats %.1f) us | '
-          'out %.0f MB | rel diff %.1e' % (S, S, t0, t1, t2, t3, t4, t5, t6, mb, err))
+    b = torch.randn(C, device=dev)
+    res = ops.nhwc_empty(N, C, H, H, torch.bfloat16, dev).normal_()
+    o1 = ops.pw_k2c(y, w, b, C, torch.bfloat16)
+    o2 = ops.pw_k2c(y, w, b, C, torch.bfloat16, residual=res)
+    o3, _ = ops.pw_k2c_stats(y, w, b, C, torch.bfloat16, residual=res)
+    ref = torch.einsum('nkhw,ck->nchw', y, w) + b.view(1, -1, 1, 1)
+    e1 = float((o1.float() - ref).abs().max())
+    import hashlib
+    h = hashlib.md5(o2.cpu().view(torch.int16).numpy().tobytes()).hexdigest()[:8]
+    t1 = timeit(lambda: ops.pw_k2c(y, w, b, C, torch.bfloat16))
+    t2 = timeit(lambda: ops.pw_k2c(y, w, b, C, torch.bfloat16, residual=res))
+    t3 = timeit(lambda: ops.pw_k2c_stats(y, w, b, C, torch.bfloat16, residual=res))
+    print('%s k2c N%d H%d C%d K%d: plain %.1f us, +res %.1f us, +res+stats %.1f us  err %.2e md5 %s' % (tag, N, H, C, K, t1*1e6, t2*1e6, t3*1e6, e1, h), flush=True)
