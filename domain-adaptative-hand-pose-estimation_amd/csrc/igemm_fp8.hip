@@ -1,14 +1,16 @@
 // fp8 operand path of the implicit-GEMM convolution family (gfx950, OCP e4m3 / e5m2, fp32 accumulate, bf16 out).
 //
 // Why: the bf16 gather kernel is bounded by the bytes its tiles pull through the CU's vector-memory path per MFMA
-// (~0.5 KB / MFMA at a sustained ~15 TB/s of tile fills).  v_mfma_f32_32x32x16_fp8_fp8 has the
-// cycles of the bf16 instruction at the same K, so a 128-byte LDS row now carries 128 channels instead of 64: the same
-// staged bytes, the same ds_read_b128 stream, twice the MFMA work.  A lane's 16-byte fragment read feeds TWO MFMAs (low /
-// high 8 bytes); both operands use the same lane -> k assignment, so any k order is consistent.
+// (~0.5 KB / MFMA at a sustained ~15 TB/s of tile fills).  A 128-byte LDS row carries 128 fp8 channels
+// instead of 64 bf16 ones -- the same staged bytes and the same ds_read_b128 stream for twice the contraction -- and the K = 64
+// instruction v_mfma_f32_32x32x64_f8f6f4 (16 passes) does that contraction at twice the rate of the K = 16 fp8 MFMA, which has
+// the cycles of the bf16 one.  A lane's two 16-byte fragment reads of a row are the 32 bytes of one operand; both operands use
+// the same lane -> k assignment, so any k order is consistent (profiles/mx_mfma_probe.hip).
 //
 // Also here: per-tensor scaled quantisation bf16 / fp32 -> fp8 with amax tracking (delayed scaling: quantise with the
 // scale derived from the previous amax while recording the current one; `mi355_fp8_amax` + `mi355_fp8_update_scale` give
-// the just-in-time form), and the fp8 weight pack ([O][T][I] and [I][T][O], per-tensor scale).
+// the just-in-time form; every copy carries the descale it was made with, fp8_common.h), and the fp8 weight pack ([O][T][I]
+// and [I][T][O], per-tensor scale).  The weight-gradient kernels on fp8 operands are in wgrad_fp8.hip.
 #include "igemm_common.h"
 #include "fp8_common.h"
 #include <stdlib.h>
