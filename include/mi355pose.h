@@ -115,15 +115,20 @@ int mi355_conv_fwd_bnbwd(const mi355_conv_desc* d, const void* x, const void* w,
 /* ---- fp8 operand path (BASELINE config 5: "fp8 conv MFMA path"; reference layers: the K-heavy 3x3 / 4x4 convolutions
  * of uda/model/regda_7.py:4906-4929, pose_resnet2.py:33-41 and the torchvision Bottleneck 3x3).  OCP formats:
  * fmt 0 = e4m3 (activations, weights), fmt 1 = e5m2 (gradients).  Per-tensor scaling state = 4 floats on the device:
- * {scale, descale = 1/scale, amax bits (max |x| seen since the last update), unused}.
+ * {scale, descale = 1/scale, amax bits (max |x| seen since the last update), descale of the latest weight pack made with it}.
+ * A copy must be descaled with the scale it was MADE with: the state is refreshed at every optimizer step and a copy may be
+ * consumed after that, so activation copies carry their own record (write = 2 below) and weight packs leave theirs in state[3].
  *
  * mi355_fp8_quantize: q[i] = saturate_fmt(x[i] * state[0]) for i < n (n a multiple of 16; x bf16 or fp32), and
- *   state[2] = max(state[2], max |x|) -- with write = 0 only the amax is taken (just-in-time scaling: amax, update, quantise).
+ *   state[2] = max(state[2], max |x|) -- with write = 0 only the amax is taken (just-in-time scaling: amax, update, quantise);
+ *   write = 2: q has 16 more bytes behind its n, which receive this copy's own record {scale, descale, 0, 0} (usable wherever
+ *   a state's descale is read).
  * mi355_fp8_update_scale: for each of n states (stride_floats apart): scale = 2^floor(log2(fmt_max / (amax * 2^margin)))
  *   (kept when no amax was recorded; 1 if never set), descale = 1/scale, amax = 0.
  * mi355_pack_weights_fp8: fp32 master [O][T][I] -> e4m3 wf [O][T][I] and wt [I][T][O] (O, I multiples of 32).  margin >= 0:
  *   just-in-time per-tensor scale from amax(|w|), left in `state`; margin < 0: the scale already in `state` (delayed
- *   scaling).  Either way amax(|w|) is recorded in state[2] for the next mi355_fp8_update_scale. */
+ *   scaling).  Either way amax(|w|) is recorded in state[2] for the next mi355_fp8_update_scale, and state[3] = the descale
+ *   this pack was made with (what its consumers must read). */
 int mi355_fp8_quantize(const void* x, void* q, float* state, long n, int src_dtype, int fmt, int write, void* stream);
 int mi355_fp8_update_scale(float* states, int n, int stride_floats, int fmt, int margin, void* stream);
 int mi355_pack_weights_fp8(const float* w, void* wf, void* wt, float* state, int O, int T, int I, int margin, void* stream);
