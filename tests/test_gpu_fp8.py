@@ -276,6 +276,31 @@ def test_conv_wgrad_fp8_stride2_vs_fp64_on_rounded_operands(gpu, case):
     assert err <= 2e-4, 'wgrad_fp8 s2 %s: %.3e' % (case, err)
 
 
+def test_fp8_copies_keep_the_scale_they_were_made_with(gpu):
+    """The stream state is refreshed at every optimizer step; a copy (or a weight pack) made before a refresh and consumed after
+    it must be descaled with ITS scale: the record behind the copy (q._mi_rec) / state[3] of the pack, not the live state[1]."""
+    ops = _ops()
+    N, H, W, C = 2, 16, 16, 128
+    x = _nhwc(randn(71, N, C, H, W).to(gpu).to(torch.bfloat16))
+    w_conv = (randn(72, C, 3, 3, C) / np.sqrt(C * 9)).to(gpu)
+    sx, sw = ops.fp8_state(gpu), ops.fp8_state(gpu)
+    x8 = ops.fp8_quantize(x, sx, ops.E4M3, jit=True)
+    rec = x8._mi_rec
+    wf8, wt8 = ops.pack_weights_fp8(w_conv, C, 9, C, sw)
+    assert float(rec[0]) == float(sx[0]) and float(rec[1]) == float(sx[1]) and float(sw[3]) == float(sw[1])
+    desc = ops.make_desc_fp8(N, H, W, C, C, 3, 3, 1, 1)
+    y0 = ops.conv_fwd_fp8(desc, x8, rec, wf8, sw[2:4])
+    # the scale refresh after a step in which both streams saw values 64 times larger
+    ops.fp8_amax((x.float() * 64).to(torch.bfloat16), sx); ops.fp8_update_scale(sx, 1, ops.E4M3)
+    ops.fp8_amax(w_conv * 64, sw); ops.fp8_update_scale(sw, 1, ops.E4M3)
+    torch.cuda.synchronize()
+    assert float(sx[1]) == 64 * float(rec[1]) and float(sw[1]) == 64 * float(sw[3])      # live scales moved, records did not
+    y1 = ops.conv_fwd_fp8(desc, x8, rec, wf8, sw[2:4])
+    assert torch.equal(y0, y1)
+    y_live = ops.conv_fwd_fp8(desc, x8, sx, wf8, sw)                                        # what reading the live state gives
+    assert float((y_live.float() - 4096 * y0.float()).abs().max()) <= 0.02 * float(y_live.float().abs().max())
+
+
 def test_fp8_argument_checks_are_loud(gpu):
     import mi355
     ops = _ops()
