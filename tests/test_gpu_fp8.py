@@ -379,7 +379,7 @@ def test_fp8_layers_track_the_bf16_layers(gpu, fp8_mode, kind, k, s, p, wgrad8, 
     assert torch.allclose(bn.running_var, bn2.running_var, rtol=1e-4, atol=1e-6)
 
 
-def test_fp8_resnet101_forward_and_resnet50_iteration_vs_reference(gpu, fp8_mode):
+def test_fp8_resnet101_forward_and_resnet50_iteration_vs_reference(gpu, fp8_mode, monkeypatch):
     """Model level against golden G8 (the reference's own classes in fp32).  Eval-mode forward of ResNet-101 (B=2, 256x256;
     in 'fp8' mode 33 backbone 3x3 convs, the 3 transposed convs and the head's 3x3 conv run on fp8 operands): heat-maps
     within 6e-2 of the reference (relative L2; measured 0.021, bf16 mode on the same fixture 0.003, both printed).  Train-mode forwards of this
@@ -389,6 +389,9 @@ def test_fp8_resnet101_forward_and_resnet50_iteration_vs_reference(gpu, fp8_mode
     from conftest import golden
     from test_gpu_model import _g8_setup, _g8_batch
     from mi355.da_step import build_training
+    import mi355.nn as mnn
+    monkeypatch.setattr(mnn, '_FP8_EVAL', True)             # (opt-in MI355_FP8_EVAL: eval-mode convs on fp8 operands; default: folded bf16)
+    monkeypatch.setattr(mnn, '_FP8_DECONV', True)
     mi355 = fp8_mode
     g = golden('g8_bottleneck')
     ref = torch.from_numpy(g['r101_y_eval'])
@@ -421,6 +424,27 @@ def test_fp8_resnet101_forward_and_resnet50_iteration_vs_reference(gpu, fp8_mode
             # (a zero-initialised conv bias in front of a training-mode BatchNorm has an exactly zero gradient: it may stay put)
             inert = k.endswith('.bias') and p.grad is not None and float(p.grad.abs().max()) == 0.0 and float(before[k].abs().max()) == 0.0
             assert torch.isfinite(p).all() and (inert or not torch.equal(p, before[k])), k
+
+
+def test_fp8_mode_inference_takes_the_folded_bf16_path(gpu, fp8_mode):
+    """'fp8' mode accelerates the training GEMMs; an eval-mode forward is the BatchNorm-folded bf16 path of 'bf16' mode, bit for bit
+    (MI355_FP8_EVAL=1 puts eval-mode convs on fp8 operands instead: exercised by the ResNet-101 test above)."""
+    from test_gpu_model import _g8_setup
+    mi355 = fp8_mode
+    mi355.set_compute_dtype('bf16')
+    m = _g8_setup(gpu, 'resnet50', 811)
+    x = randn(813, 2, 3, 256, 256).to(gpu)
+    m.train()
+    with torch.no_grad():
+        m(x)                                          # running statistics away from their initial values
+    m.eval()
+    outs = {}
+    for dt in ('bf16', 'fp8'):
+        mi355.set_compute_dtype(dt)
+        with torch.no_grad():
+            y = m(x)
+        outs[dt] = (y[0] if isinstance(y, (tuple, list)) else y).float().clone()
+    assert torch.isfinite(outs['fp8']).all() and torch.equal(outs['bf16'], outs['fp8'])
 
 
 @pytest.mark.parametrize('wgrad8', [False, True])
