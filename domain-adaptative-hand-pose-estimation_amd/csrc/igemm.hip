@@ -35,8 +35,10 @@ struct GatherSmem {
 //      fewer bytes through L1 and LDS per MFMA.  The LDS A image keeps every run of min(W,128) pixels in a segment of its
 //      own with spare zero rows between segments, so a shifted fragment read sees zeros exactly at the image border
 //      (same construction as wgrad_kw_kernel).
+// CAT: one more K tile behind the conv's own taps, gathered from a second operand pair (A2 [M][c2] at the output resolution,
+//      B2 [Nout][c2]; channels c2 .. BK-1 of that tile are out-of-range lanes = zeros): y = conv(x, w) + A2 * B2^T as ONE GEMM.
 template <typename T, int BM, int BN, bool SMALL_C, int WGM = 2, int WGN = 2, bool HM_OUT = false, bool DMA = false, int EPI = 0,
-          bool KW3 = false>
+          bool KW3 = false, bool CAT = false>
 __global__ __launch_bounds__(64 * WGM * WGN, (KW3 && BM == 256) ? 2 : 1) void gather_gemm_kernel(const GatherArgs p) {
   constexpr int CH = MmaTraits<T>::CH;
   constexpr int NTHR = 64 * WGM * WGN, RPP = NTHR / 8;      // rows staged per pass (8 lanes = one 128-byte row)
@@ -45,6 +47,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, (KW3 && BM == 256) ? 2 : 1) void ga
   using SM = GatherSmem<T, BM, BN, DMA ? 2 : 1, KW3>;
   static_assert(!KW3 || (!DMA && !SMALL_C && !HM_OUT && sizeof(T) == 2), "KW3 is a bf16 variant of the plain large-channel kernel");
   static_assert(!DMA || !SMALL_C, "the LDS-DMA pipeline is built for the large-channel path");
+  static_assert(!CAT || (!SMALL_C && !HM_OUT && !KW3 && EPI != 2), "CAT: plain large-channel forward (register-staged or LDS-DMA)");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   int* row_off = reinterpret_cast<int*>(smem + SM::kBytes - BM * 4);
 
@@ -60,6 +63,8 @@ __global__ __launch_bounds__(64 * WGM * WGN, (KW3 && BM == 256) ? 2 : 1) void ga
   const int lc = t & 7, lr = t >> 3;
 
   const __amdgpu_buffer_rsrc_t rsA = make_rsrc(p.A, p.a_bytes), rsB = make_rsrc(p.B, p.b_bytes);
+  const __amdgpu_buffer_rsrc_t rsA2 = make_rsrc(CAT ? p.A2 : p.A, CAT ? p.a2_bytes : 0u), rsB2 = make_rsrc(CAT ? p.B2 : p.B, CAT ? p.b2_bytes : 0u);
+  const int nk_main = (pkchunks + 7) >> 3;            // K tiles of the conv's own taps; the CAT tile is K tile number nk_main
 
   // decode this thread's A rows once
   int iy0[RA], ix0[RA], abase[RA];
@@ -91,8 +96,24 @@ __global__ __launch_bounds__(64 * WGM * WGN, (KW3 && BM == 256) ? 2 : 1) void ga
   int pix0[RA];
 #pragma unroll
   for (int i = 0; i < RA; ++i) pix0[i] = iy0[i] >= 0 ? (abase[i] + iy0[i] * p.Wi + ix0[i]) * p.Ci : 0;
-  auto tap_of = [&](int kt) -> Tap { return ptaps[(kt * 8) >> p.cshift]; };     // (large-channel path: one tap per K-tile)
+  auto tap_of = [&](int kt) -> Tap { return ptaps[((CAT && kt >= nk_main ? nk_main - 1 : kt) * 8) >> p.cshift]; };     // (large-channel path: one tap per K-tile)
   auto load_tile = [&](int kt, const Tap tpu, uint4 (&ra)[RA], uint4 (&rb)[RB]) {
+    if constexpr (CAT) {
+      if (kt == nk_main) {              // block-uniform: the second operand pair, chunk lc of row m / output channel n
+        const bool okc = lc * CH < p.c2;
+#pragma unroll
+        for (int i = 0; i < RA; ++i) {
+          const int m = m0 + lr + RPP * i;
+          ra[i] = buf_load16(rsA2, (okc && m < pM) ? (m * p.c2 + lc * CH) * (int)sizeof(T) : OOB_OFF);
+        }
+#pragma unroll
+        for (int i = 0; i < RB; ++i) {
+          const int n = n0 + lr + RPP * i;
+          rb[i] = buf_load16(rsB2, (okc && n < p.Nout) ? (n * p.c2 + lc * CH) * (int)sizeof(T) : OOB_OFF);
+        }
+        return;
+      }
+    }
     if constexpr (SMALL_C) {
       const int q = kt * 8 + lc; const bool okq = q < pkchunks; const int tap = okq ? (q >> p.cshift) : 0; const int cc = (q & cmask) * CH;
       const Tap tp = ptaps[tap];
@@ -130,7 +151,8 @@ __global__ __launch_bounds__(64 * WGM * WGN, (KW3 && BM == 256) ? 2 : 1) void ga
   const int lcs = lc ^ ((lr >> 1) & 7);
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
   auto dma_tile = [&](int kt, int stage) {
-    const int q0 = kt * 8, tap = q0 >> p.cshift;
+    const bool cat = CAT && kt == nk_main;            // block-uniform
+    const int q0 = (cat ? 0 : kt) * 8, tap = q0 >> p.cshift;
     const int cc = ((q0 & cmask) + lcs) * CH;
     const Tap tp = ptaps[tap];
     const int koff = (int)tp.widx * p.Ci + cc;
@@ -140,6 +162,24 @@ __global__ __launch_bounds__(64 * WGM * WGN, (KW3 && BM == 256) ? 2 : 1) void ga
     typedef __attribute__((address_space(3))) void* ldsp;
     char* sa = smem + stage * SM::kStage + wave_u * 1024;
     char* sb = sa + BM * 128;
+    if constexpr (CAT) {
+      if (cat) {                                      // logical chunk lcs of row m / output channel n of the second operand pair
+        const bool okc = lcs * CH < p.c2;
+#pragma unroll
+        for (int i = 0; i < RA; ++i) {
+          const int m = m0 + lr + RPP * i;
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA2, (ldsp)(sa + i * RPP * 128), 16,
+                                                   (okc && m < pM) ? (m * p.c2 + lcs * CH) * (int)sizeof(T) : OOB_OFF, 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < RB; ++i) {
+          const int n = n0 + lr + RPP * i;
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB2, (ldsp)(sb + i * RPP * 128), 16,
+                                                   (okc && n < p.Nout) ? (n * p.c2 + lcs * CH) * (int)sizeof(T) : OOB_OFF, 0, 0, 0);
+        }
+        return;
+      }
+    }
 #pragma unroll
     for (int i = 0; i < RA; ++i) {
       int iy = iy0[i] + tp.dy, ix = ix0[i] + tp.dx;
@@ -205,7 +245,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, (KW3 && BM == 256) ? 2 : 1) void ga
     }
   };
 
-  const int nk = (pkchunks + 7) >> 3;
+  const int nk = nk_main + (CAT ? 1 : 0);
   if constexpr (KW3) {
     // sub-step ks = (group g, kw), group g = (kernel row kh, channel chunk): tap index kh*3 + kw, channels chunk*64 ..
     const int nchunk = p.Ci >> 6, nsub = 9 * nchunk;
@@ -347,6 +387,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, (KW3 && BM == 256) ? 2 : 1) void ga
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           float b = (p.bias && (n0 + nl + e) < p.Nout) ? p.bias[n0 + nl + e] : 0.f;
+          if constexpr (CAT) { if (p.bias2 && (n0 + nl + e) < p.Nout) b += p.bias2[n0 + nl + e]; }
           v[e] = (acc[i][j][4 * g + e] + b) * scale;
         }
         char* dst = outs + ml * SM::kOutStride + nl * (int)sizeof(T);
@@ -1129,16 +1170,16 @@ __global__ void zero_fill_kernel(uint4* __restrict__ p, size_t n16) {
 // ------------------------------------------------------------------------------------ host side
 static int ilog2_exact(int v) { int s = 0; while ((1 << s) < v) ++s; return ((1 << s) == v) ? s : -1; }
 
-template <typename T, int BM, int BN, bool SMALL_C, int WGM, int WGN, bool HM_OUT, bool DMA, int EPI, bool KW3 = false>
+template <typename T, int BM, int BN, bool SMALL_C, int WGM, int WGN, bool HM_OUT, bool DMA, int EPI, bool KW3 = false, bool CAT = false>
 static void launch_gather_epi(const GatherArgs& a, hipStream_t st) {
   constexpr int smem = GatherSmem<T, BM, BN, DMA ? 2 : 1, KW3>::kBytes;
-  auto kern = gather_gemm_kernel<T, BM, BN, SMALL_C, WGM, WGN, HM_OUT, DMA, EPI, KW3>;
+  auto kern = gather_gemm_kernel<T, BM, BN, SMALL_C, WGM, WGN, HM_OUT, DMA, EPI, KW3, CAT>;
   static bool attr_set = false;   // raise the dynamic-LDS cap once per instantiation
   if (!attr_set) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem); attr_set = true; }
   hipLaunchKernelGGL(kern, dim3(a.ntiles), dim3(64 * WGM * WGN), smem, st, a);
 }
 
-template <typename T, int BM, int BN, bool SMALL_C, int WGM = 2, int WGN = 2, bool HM_OUT = false, bool DMA = false, bool KW3 = false>
+template <typename T, int BM, int BN, bool SMALL_C, int WGM = 2, int WGN = 2, bool HM_OUT = false, bool DMA = false, bool KW3 = false, bool CAT = false>
 static void launch_gather(GatherArgs& a, hipStream_t st) {
   a.ntn = cdiv(a.Nout, BN);
   int mx = 0;
@@ -1157,7 +1198,7 @@ static void launch_gather(GatherArgs& a, hipStream_t st) {
     if (even && (size_t)a.nphase * mx * a.Nout * 2 * sizeof(float) <= a.stat_bytes) a.stat_slices = a.nphase * mx;
     else a.bnb_partial = nullptr;
   }
-  constexpr bool EXTRAS = !HM_OUT && BM <= 128;     // the BatchNorm-backward epilogue exists for the regular tiles only
+  constexpr bool EXTRAS = !HM_OUT && BM <= 128 && !CAT;     // the BatchNorm-backward epilogue exists for the regular tiles only
   constexpr bool STATS = !HM_OUT && (BM <= 128 || (BM == 256 && BN == 128));   // statistics: also the 256x128 macro tile
   if (!EXTRAS && a.bnb_partial) a.bnb_partial = nullptr;
   static const bool stats256 = !(getenv("MI355_STATS_256") && atoi(getenv("MI355_STATS_256")) == 0);      // A/B switch
@@ -1167,9 +1208,9 @@ static void launch_gather(GatherArgs& a, hipStream_t st) {
     if (a.bnb_partial) { launch_gather_epi<T, BM, BN, SMALL_C, WGM, WGN, HM_OUT, DMA, 2>(a, st); return; }     // (EPI 2 has no KW3 build)
   }
   if constexpr (STATS) {
-    if (a.stat_partial) { launch_gather_epi<T, BM, BN, SMALL_C, WGM, WGN, HM_OUT, DMA, 1, KW3>(a, st); return; }
+    if (a.stat_partial) { launch_gather_epi<T, BM, BN, SMALL_C, WGM, WGN, HM_OUT, DMA, 1, KW3, CAT>(a, st); return; }
   }
-  launch_gather_epi<T, BM, BN, SMALL_C, WGM, WGN, HM_OUT, DMA, 0, KW3>(a, st);
+  launch_gather_epi<T, BM, BN, SMALL_C, WGM, WGN, HM_OUT, DMA, 0, KW3, CAT>(a, st);
 }
 
 template <typename T>
@@ -1196,12 +1237,30 @@ static int dispatch_gather(GatherArgs& a, hipStream_t st) {
   const long kavg = (ntaps_tot << a.cshift) / a.nphase;   // phases of a strided dgrad differ in length
   (void)kchunks;
   // algorithmic bytes: every input element, weight and output element once
-  ProfScope ps(st, flops, (double)a.a_bytes + (double)a.b_bytes * ntaps_tot / (a.ldb / a.Ci) + (double)Mtot * a.Nout * sizeof(T));
+  if (a.A2) flops += 2.0 * Mtot * (double)a.Nout * a.c2;
+  ProfScope ps(st, flops, (double)a.a_bytes + (double)a.b_bytes * ntaps_tot / (a.ldb / a.Ci) + (double)Mtot * a.Nout * sizeof(T) +
+                              (a.A2 ? (double)a.a2_bytes + a.b2_bytes : 0.0));
+  static const int force = getenv("MI355_TILE") ? atoi(getenv("MI355_TILE")) : -1;   // experiment switch
+  static const int dma_mode = getenv("MI355_DMA") ? atoi(getenv("MI355_DMA")) : 1;
+  if (a.A2) {
+    // concatenated-K forward: the tile choices of the plain path that matter for the two layers that use it (1x1 and 3x3 / stride 2,
+    // 256 -> 256 channels), register-staged or LDS-DMA ring
+    if (small || a.nphase != 1 || a.out_sx != 1 || a.out_sy != 1 || a.bnb_partial || a.residual || a.accumulate)
+      MI_FAIL(MI355_EINVAL, "concat-K forward: plain single-phase forward conv with >= 8 input chunks only");
+    if (a.c2 < CH || a.c2 % CH || a.c2 > MmaTraits<T>::BK) MI_FAIL(MI355_EINVAL, "concat-K forward: c2=%d must be a multiple of %d and <= %d", a.c2, CH, MmaTraits<T>::BK);
+    const long t128 = cdiv(Mtot, 128L) * cdiv(a.Nout, 128);
+    if (a.Nout <= 64) launch_gather<T, 64, 64, false, 2, 2, false, false, false, true>(a, st);
+    else if ((dma_mode == 2) || (dma_mode == 1 && ((t128 >= 512 && kavg >= 128) || (t128 >= 256 && kavg >= 256)))) launch_gather<T, 128, 128, false, 2, 2, false, true, false, true>(a, st);
+    else if (t128 >= 512 && kavg <= 32 && sizeof(T) == 2) launch_gather<T, 64, 128, false, 2, 2, false, false, false, true>(a, st);
+    else if (t128 >= 512) launch_gather<T, 128, 128, false, 2, 2, false, false, false, true>(a, st);
+    else if (cdiv(Mtot, 64L) * cdiv(a.Nout, 128) >= 512) launch_gather<T, 64, 128, false, 2, 2, false, false, false, true>(a, st);
+    else launch_gather<T, 64, 64, false, 2, 2, false, false, false, true>(a, st);
+    MI_CHECK_LAUNCH("gather_gemm_cat");
+    return MI355_OK;
+  }
   if constexpr (sizeof(T) == 2) {
     if (pgemm_eligible(a, 2)) return dispatch_pgemm(a, st);       // 1x1 / unit stride: the persistent pipelined GEMM (pgemm.hip)
   }
-  static const int force = getenv("MI355_TILE") ? atoi(getenv("MI355_TILE")) : -1;   // experiment switch
-  static const int dma_mode = getenv("MI355_DMA") ? atoi(getenv("MI355_DMA")) : 1;
   if (small) { launch_gather<T, 128, 64, true>(a, st); }
   else if (force == 0) launch_gather<T, 128, 128, false>(a, st);
   else if (force == 1) launch_gather<T, 64, 128, false>(a, st);
@@ -1273,9 +1332,10 @@ static int check_bnb(const mi355_bn_bwd_src* bn, const float* partial, const int
 }
 // fp8 operand launches: device scalars undoing the operand scales, and the format of the gathered operand
 struct Fp8Extra { const float* descale_a; const float* descale_b; int a_fmt; };
+struct CatExtra { const void* x2; const void* w2; const float* bias2; int c2; };
 static int conv_fwd_impl(const mi355_conv_desc* d, const void* x, const void* w, const float* bias, const void* residual, void* y,
                          float* partial, size_t partial_bytes, int* nslices, void* stream, const mi355_bn_bwd_src* bn = nullptr,
-                         const Fp8Extra* f8 = nullptr, int relu = 0) {
+                         const Fp8Extra* f8 = nullptr, int relu = 0, const CatExtra* cat = nullptr) {
   if (int e = check_desc(d)) return e;
   if ((d->dtype == MI355_FP8) != (f8 != nullptr)) MI_FAIL(MI355_EINVAL, "fp8 descriptors go through the *_fp8 entry points (and only they)");
   if (relu && (bn || f8 || partial)) MI_FAIL(MI355_EINVAL, "conv_fwd: the fused ReLU is an inference epilogue (no statistics / BatchNorm-backward / fp8 variant)");
@@ -1288,6 +1348,11 @@ static int conv_fwd_impl(const mi355_conv_desc* d, const void* x, const void* w,
   a.nphase = 1; a.ph[0].OHp = d->Ho; a.ph[0].OWp = d->Wo; a.ph[0].M = d->N * d->Ho * d->Wo; a.ph[0].ntaps = d->kh * d->kw;
   if (bn) set_bnb(a, bn, partial, partial_bytes);
   else { a.stat_partial = partial; a.stat_bytes = partial_bytes; }
+  if (cat) {
+    const long esz = d->dtype == MI355_F32 ? 4 : 2;
+    a.A2 = cat->x2; a.B2 = cat->w2; a.bias2 = cat->bias2; a.c2 = cat->c2;
+    a.a2_bytes = (unsigned)((long)d->N * d->Ho * d->Wo * cat->c2 * esz); a.b2_bytes = (unsigned)((long)d->Co * cat->c2 * esz);
+  }
   for (int i = 0; i < d->kh; ++i)
     for (int j = 0; j < d->kw; ++j) { Tap& t = a.taps[i * d->kw + j]; t.dy = (int8_t)(i - d->pad); t.dx = (int8_t)(j - d->pad); t.widx = (int16_t)(i * d->kw + j); }
   int e;
@@ -1317,6 +1382,19 @@ extern "C" int mi355_conv_fwd_stats(const mi355_conv_desc* d, const void* x, con
                                     float* partial, size_t partial_bytes, int* nslices, void* stream) {
   if (!partial || !nslices) MI_FAIL(MI355_EINVAL, "conv_fwd_stats: partial / nslices must be given");
   return conv_fwd_impl(d, x, w, bias, nullptr, y, partial, partial_bytes, nslices, stream);
+}
+// y = conv(x, w) + x2 * w2^T + bias + bias2 as ONE implicit GEMM (K = kh*kw*Ci + c2): x2 [N*Ho*Wo][c2] at the OUTPUT resolution,
+// w2 [Co][c2], both in the descriptor's dtype, c2 a multiple of the 16-byte chunk and <= one K tile (64 bf16 / 32 fp32).
+// partial / nslices: nullable pair, BatchNorm statistics of y from the epilogue as in mi355_conv_fwd_stats.
+extern "C" int mi355_conv_fwd_cat(const mi355_conv_desc* d, const void* x, const void* w, const float* bias, const void* x2,
+                                  const void* w2, const float* bias2, int c2, void* y, float* partial, size_t partial_bytes,
+                                  int* nslices, void* stream) {
+  if (!x2 || !w2 || c2 < 1) MI_FAIL(MI355_EINVAL, "conv_fwd_cat: second operand pair missing");
+  if ((partial == nullptr) != (nslices == nullptr)) MI_FAIL(MI355_EINVAL, "conv_fwd_cat: partial and nslices go together");
+  if (d && d->dtype == MI355_FP8) MI_FAIL(MI355_EINVAL, "conv_fwd_cat: bf16 / fp32 descriptors only");
+  if (nslices) *nslices = 0;
+  CatExtra cat{x2, w2, bias2, c2};
+  return conv_fwd_impl(d, x, w, bias, nullptr, y, partial, partial_bytes, nslices, stream, nullptr, nullptr, 0, &cat);
 }
 // ConvTranspose2d input gradient (= conv-form forward) producing the dy of a BatchNorm: its backward reduction in the epilogue
 extern "C" int mi355_conv_fwd_bnbwd(const mi355_conv_desc* d, const void* x, const void* w, void* y, const mi355_bn_bwd_src* bn,

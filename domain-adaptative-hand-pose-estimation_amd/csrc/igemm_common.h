@@ -42,6 +42,11 @@ struct GatherArgs {
   // chunk * chunk_size + e: the ReLU bit mask of BatchNorm's forward) -- D + this launch's result = masked fork gradient
   const unsigned char* acc_mask;
   int relu;                    // max(0, .) on the finished value (inference: conv + folded BatchNorm + ReLU in one launch)
+  // Concatenated-K forward (CAT builds of the gather kernel): D += A2 * B2^T as ONE more K tile behind the conv's own taps --
+  // A2 [M][c2] lives at the OUTPUT resolution (row m = output pixel m: single phase, unit output stride), B2 [Nout][c2],
+  // c2 <= one K tile.  `heatmap_conv(y) + feature_conv(f)` of the multiscale-fusion heads as one GEMM (regda_7.py:4573-4581).
+  const void* A2; const void* B2; const float* bias2;
+  int c2; unsigned a2_bytes, b2_bytes;
 };
 
 // 16-byte chunk with the elements whose mask bit is clear set to zero (bit e = element e; bf16: two elements per word)

@@ -51,6 +51,7 @@ SIGNATURES = {
     'mi355_conv_stats_bytes': (_Z, [_L, _I]),
     'mi355_conv_fwd_stats': (_I, [_D, _P, _P, _P, _P, _P, _Z, _P, _P]),
     'mi355_conv_dgrad_stats': (_I, [_D, _P, _P, _P, _P, _Z, _P, _P]),
+    'mi355_conv_fwd_cat': (_I, [_D, _P, _P, _P, _P, _P, _P, _I, _P, _P, _Z, _P, _P]),
     'mi355_conv_dgrad_bnbwd': (_I, [_D, _P, _P, _P, _I, _P, _P, _P, _Z, _P, _P]),
     'mi355_conv_fwd_bnbwd': (_I, [_D, _P, _P, _P, _P, _P, _Z, _P, _P]),
     'mi355_fp8_quantize': (_I, [_P, _P, _P, _L, _I, _I, _I, _P]),

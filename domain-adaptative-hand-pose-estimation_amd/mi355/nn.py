@@ -733,11 +733,12 @@ class _CastCopy:
         return self.buf
 
 
-def _pw_wgrad_mfma(feat, hm, g, acc, kc_layout):
+def _pw_wgrad_mfma(feat, hm, g, acc, kc_layout, K=None):
     """Weight gradient of a 1x1 conv between NHWC features `feat` [N,C,H,W] and heat-maps `hm` [N,K,H,W] on the
-    MFMA wgrad kernel: the heat-map operand is re-laid as NHWC with K padded to 32 channels (16 MB at B=64)."""
+    MFMA wgrad kernel: the heat-map operand is re-laid as NHWC with K padded to 32 channels (16 MB at B=64); a caller that
+    kept that 32-channel copy from its forward passes it as `hm` together with the real K."""
     N, C, H, W = feat.shape
-    K = hm.shape[1]
+    K = hm.shape[1] if K is None else K
     hm32 = ops.to_nhwc(hm, feat.dtype, 32)
     tmp = torch.empty(32 * C, dtype=torch.float32, device=feat.device)
     if kc_layout:      # dW[k][c] = sum_p hm[p][k] * feat[p][c]  : conv-form x=feat (Ci=C), dy=hm32 (Co=32)
@@ -822,6 +823,76 @@ class _PwK2CFn(torch.autograd.Function):
             _bias_grad(ctx, bias, dout)
         dres = dout if ctx.needs_input_grad[3] else None
         return dhm, None, None, dres, None, None
+
+
+_CAT = _os.environ.get('MI355_CAT', '1') == '1'      # A/B switch: heat-map conv + feature conv of the fusion heads as one concat-K GEMM
+
+
+class _ConvCatFn(torch.autograd.Function):
+    """``heatmap_conv(heatmap) + feature_conv(feature)`` at the entry of the multiscale-fusion heads (reference
+    uda/model/regda_7.py:4573-4581, :4649-4662) as ONE implicit GEMM with K = kh*kw*256 + 32: the 21-channel NCHW fp32 heat-map is
+    re-laid once as a 32-channel NHWC operand (the copy the heat-map conv's weight gradient needs anyway) and travels as one more
+    K tile of the feature conv (mi355_conv_fwd_cat), with both biases and the BatchNorm statistics in the epilogue.  The 134-MB
+    feature-conv output is neither written nor re-read by a separate 21 -> 256 pass.  Backward = the two convs' own backward
+    kernels on the shared output gradient."""
+
+    @staticmethod
+    def forward(ctx, x, hm, wf, bf, wh, bh, fmod, hmod, scale_dev, fan):
+        desc, wpk, _ = fmod._plan(x)
+        K = hmod.in_channels
+        hm32 = ops.to_nhwc(hm, x.dtype, 32)
+        w2, _ = hmod._packed.get(wh, hmod.out_channels, 1, K, 32, x.dtype)
+        w2 = w2.view(hmod.out_channels, 32)
+        want = hmod._want_stats()
+        if want:
+            y, part = ops.conv_fwd_cat(desc, x, wpk, bf, hm32, w2, bh, want_stats=True)
+        else:
+            y, part = ops.conv_fwd_cat(desc, x, wpk, bf, hm32, w2, bh), None
+        ctx.mod, ctx.desc, ctx.hmod, ctx.K = fmod, desc, hmod, K
+        ctx.fp8, ctx.bn_src = False, None
+        ctx.fan, ctx.scale_dev = fan, scale_dev
+        ctx.has_bias = bf is not None or bh is not None
+        ctx.save_for_backward(x, hm32, wf, bf, wh, bh)
+        # the hand-off _take_partial reads: the statistics, and the context whose bias gradients the BatchNorm declares zero
+        hmod._last_partial = part
+        hmod._last_bias_ctx = ctx if (part is not None and ctx.has_bias) else None
+        return y
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, hm32, wf, bf, wh, bh = ctx.saved_tensors
+        fmod, hmod, K = ctx.mod, ctx.hmod, ctx.K
+        dout = _as_grad(dout, x.dtype)
+        # both bias gradients are the column sum of dout: zero when dout is the input gradient of the BatchNorm that follows
+        ent = _BN_DX.pop(dout.data_ptr(), None)
+        from_bn = ent is not None and ent.shape == dout.shape and ent.dtype == dout.dtype
+        zero = getattr(ctx, 'bias_grad_zero', False) and from_bn and _ZERO_BN_BIAS_GRAD
+        for i, b in ((3, bf), (5, bh)):
+            if b is not None and ctx.needs_input_grad[i]:
+                g, acc = grad_slot(b)
+                if zero:
+                    if not acc:
+                        g.zero_()
+                else:
+                    ops.colsum(dout, g, acc)
+        if ctx.needs_input_grad[2]:
+            _conv_wgrad(ctx, x, dout, wf)
+        if ctx.needs_input_grad[4]:
+            g, acc = grad_slot(wh)
+            _pw_wgrad_mfma(dout, hm32, g, acc, False, K=K)
+        dx = dhm = None
+        if ctx.needs_input_grad[0]:
+            fan = ctx.fan
+            onto = fan is not None and fan.buf is not None and fan.buf.shape == x.shape and fan.buf.dtype == x.dtype
+            dx = _conv_dgrad(ctx, x, dout, scale_dev=ctx.scale_dev, out=fan.buf if onto else None, accumulate=onto)
+            if onto:
+                dx = None
+            elif fan is not None:
+                fan.buf = dx
+        if ctx.needs_input_grad[1]:      # dhm[k] = sum_c dout[c] * wh[c][k]: a C -> K 1x1 conv with the transposed pack, NCHW fp32 out
+            _, wt = hmod._packed.get(wh, hmod.out_channels, 1, K, 32, dout.dtype)
+            dhm = ops.conv1x1_heatmap(dout, wt, None, K)
+        return dx, dhm, None, None, None, None, None, None, None, None
 
 
 # ---------------------------------------------------------------- modules
@@ -994,6 +1065,30 @@ class Conv2d(_FastSlots, nn.Module):
         if residual is not None:
             residual = _as_feature(residual, dtype)
         return ops.conv_fwd(desc, x, wf, bias, residual, relu=bool(relu))
+
+    def forward_cat(self, x, hm, hconv):
+        """hconv(hm) + self(x) as ONE concat-K GEMM (see _ConvCatFn), or None when this call does not qualify (the caller then runs
+        the two convs): training mode, this conv on the bf16 / fp32 MFMA kernels with unpadded input channels, hconv a 1x1 conv from
+        <= 32 heat-map channels at this conv's output resolution."""
+        dtype = compute_dtype()
+        k, s_, p_ = self.kernel_size[0], self.stride[0], self.padding[0]
+        if not (_CAT and self.training and hconv.training and self.mode == 'mfma' and hconv.mode == 'k2c' and torch.is_tensor(x) and
+                torch.is_tensor(hm) and hm.is_cuda and hm.dim() == 4 and x.dim() == 4 and
+                hconv.out_channels == self.out_channels and self.out_channels % 8 == 0 and
+                self.in_channels == self._cin_pad(dtype) and self.in_channels >= 64 and (self.in_channels & (self.in_channels - 1)) == 0):
+            return None
+        Ho, Wo = (x.shape[2] + 2 * p_ - k) // s_ + 1, (x.shape[3] + 2 * p_ - k) // s_ + 1
+        if tuple(hm.shape) != (x.shape[0], hconv.in_channels, Ho, Wo):
+            return None
+        x, scale = _claim_gl(x, dtype)
+        x = _as_feature(x, dtype)
+        if self._fp8_ok(x):
+            return None                      # ('fp8' mode: the 3x3 feature conv runs on fp8 operands, which have no concat-K build)
+        if hm.dtype != torch.float32 or not hm.is_contiguous():
+            hm = hm.float().contiguous()
+        fan = getattr(x, '_mi_fan', None) if torch.is_grad_enabled() and x.requires_grad else None
+        y = _ConvCatFn.apply(x, hm, self.weight, self.bias, hconv.weight, hconv.bias, self, hconv, scale, fan)
+        return _take_partial(hconv, y)
 
     def forward_skip(self, x):
         """(conv(x), alias of x): for residual blocks, see _ConvSkipFn.  Bias-free MFMA convs only."""

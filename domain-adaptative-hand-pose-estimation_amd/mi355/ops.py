@@ -94,6 +94,26 @@ def conv_fwd_stats(desc, x, w, bias=None):
     return y, ((partial, ns.value) if ns.value > 0 else None)
 
 
+def conv_fwd_cat(desc, x, w, bias, x2, w2, bias2, want_stats=False):
+    """y = conv(x, w) + x2 * w2^T + bias + bias2 as one implicit GEMM (mi355_conv_fwd_cat).  x2: channels_last [N, c2, Ho, Wo] at
+    the output resolution, w2: [Co, c2], both in x's dtype.  Returns y, or (y, (partial, nslices) | None) with want_stats."""
+    _chk_dev(x, w, x2, w2)
+    c2 = x2.shape[1]
+    if x2.dtype != x.dtype or w2.dtype != x.dtype or not is_nhwc(x2) or tuple(x2.shape) != (desc.N, c2, desc.Ho, desc.Wo) or \
+            tuple(w2.shape) != (desc.Co, c2) or not w2.is_contiguous():
+        raise Mi355Error('conv_fwd_cat: second operand pair must be channels_last [N, c2, Ho, Wo] / contiguous [Co, c2] in the dtype of x')
+    y = nhwc_empty(desc.N, desc.Co, desc.Ho, desc.Wo, x.dtype, x.device)
+    if not want_stats:
+        call('mi355_conv_fwd_cat', ctypes.byref(desc), ptr(x), ptr(w), ptr(bias), ptr(x2), ptr(w2), ptr(bias2), c2, ptr(y),
+             None, 0, None, stream_ptr())
+        return y
+    partial, nbytes = _stats_buf(desc.N * desc.Ho * desc.Wo, desc.Co, x.device)
+    ns = ctypes.c_int(0)
+    call('mi355_conv_fwd_cat', ctypes.byref(desc), ptr(x), ptr(w), ptr(bias), ptr(x2), ptr(w2), ptr(bias2), c2, ptr(y),
+         ptr(partial), nbytes, ctypes.byref(ns), stream_ptr())
+    return y, ((partial, ns.value) if ns.value > 0 else None)
+
+
 def conv_dgrad_stats(desc, dy, wT):
     """ConvTranspose2d forward (conv-form dgrad) + BatchNorm statistics partials of its output."""
     _chk_dev(dy, wT)

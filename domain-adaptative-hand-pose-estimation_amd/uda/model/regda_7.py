@@ -52,8 +52,11 @@ class make_head(nn.Module):
         self.last_lay = _fusion_tail(1, channel_dim)
 
     def forward(self, feature, heatmap):
-        # heatmap_conv(heatmap) + feature_conv(feature): the add is fused into the 21->256 kernel's epilogue
-        x = self.heatmap_conv(heatmap, residual=self.feature_conv(feature))
+        # heatmap_conv(heatmap) + feature_conv(feature) (reference :4575): one concat-K GEMM in training; otherwise the add is
+        # fused into the 21->256 kernel's epilogue
+        x = self.feature_conv.forward_cat(feature, heatmap, self.heatmap_conv)
+        if x is None:
+            x = self.heatmap_conv(heatmap, residual=self.feature_conv(feature))
         return self.model(self.last_lay(x))
 
 
@@ -70,7 +73,9 @@ class make_head2(nn.Module):
         self.last_lay = _fusion_tail(2 - 1, channel_dim)        # reference loops range(num_layers - 1) with 2
 
     def forward(self, feature, heatmap):
-        x = self.heatmap_conv(heatmap, residual=self.feature_conv(feature))
+        x = self.feature_conv.forward_cat(feature, heatmap, self.heatmap_conv)      # (reference :4651-4654)
+        if x is None:
+            x = self.heatmap_conv(heatmap, residual=self.feature_conv(feature))
         return self.model(self.last_lay(x))
 
 

@@ -99,6 +99,15 @@ int mi355_conv_fwd_stats(const mi355_conv_desc* d, const void* x, const void* w,
                          float* partial, size_t partial_bytes, int* nslices, void* stream);
 int mi355_conv_dgrad_stats(const mi355_conv_desc* d, const void* dy, const void* wT, void* dx, float* partial,
                            size_t partial_bytes, int* nslices, void* stream);
+/* Concatenated-K forward: y = conv(x, w) + x2 * w2^T + bias + bias2 as ONE implicit GEMM (K = kh*kw*Ci + c2).  Replaces the
+ * `heatmap_conv(heatmap) + feature_conv(feature)` pair at the entry of the multiscale-fusion heads (reference
+ * uda/model/regda_7.py:4573-4581 make_head.forward, :4649-4662 make_head2.forward) by one launch: x2 [N*Ho*Wo][c2] is the
+ * heat-map operand re-laid as NHWC at the OUTPUT resolution (mi355_nchw_to_nhwc, channels zero-padded to c2), w2 [Co][c2]
+ * the 1x1 heat-map weights, both in the descriptor's dtype (bf16 / fp32); c2 a multiple of the 16-byte chunk, <= 64 (bf16) /
+ * 32 (fp32).  bias / bias2 nullable.  partial / nslices: nullable pair, BatchNorm statistics of y as in mi355_conv_fwd_stats. */
+int mi355_conv_fwd_cat(const mi355_conv_desc* d, const void* x, const void* w, const float* bias, const void* x2,
+                       const void* w2, const float* bias2, int c2, void* y, float* partial, size_t partial_bytes,
+                       int* nslices, void* stream);
 /* The same idea for the BACKWARD pass: a GEMM whose output is the dy of a BatchNorm (the input gradient of the conv
  * that consumed the BatchNorm's output) leaves that BatchNorm's backward reduction (sum dy_eff, sum dy_eff * xhat) per
  * output-row tile in partial[slice][C][2]; mi355_bn_bwd_partials then skips its reduction pass.  bn: the BatchNorm's

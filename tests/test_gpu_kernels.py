@@ -308,6 +308,62 @@ def test_conv_epilogue_bn_statistics(gpu, dt, case):
     assert float((ya.float() - yb.float()).abs().max()) <= (2e-2 if dt == 'bf16' else 1e-4)   # bf16: one-ulp flips at most
 
 
+CAT_CASES = [
+    # N, Ci, H, W, Co, k, s, p, K : y = conv(x) + conv1x1(heat-map with K channels at the OUTPUT resolution), one case per tile choice
+    (2, 256, 16, 16, 256, 1, 1, 0, 21),     # 64 x 64 tiles, register-staged
+    (3, 64, 9, 13, 64, 3, 1, 1, 21),        # ragged rows, 64 output channels
+    (2, 256, 32, 32, 256, 3, 2, 1, 21),     # strided conv: the heat-map lives at the 16 x 16 output resolution
+    (8, 256, 64, 64, 256, 1, 1, 0, 21),     # 64 x 128 tiles (short K, many rows): make_head's shape
+    (16, 256, 64, 64, 256, 3, 2, 1, 21),    # LDS-DMA ring (K-heavy, >= 256 tiles): make_head2's shape
+    (16, 128, 32, 32, 256, 1, 1, 0, 8),     # 128 x 128 tiles register-staged, one-chunk second operand
+    (4, 64, 32, 32, 128, 3, 1, 1, 32),      # 64 x 128 tiles through the row-count rule, a full 32-channel second operand
+]
+
+
+@pytest.mark.parametrize('dt', ['f32', 'bf16'])
+@pytest.mark.parametrize('case', CAT_CASES)
+def test_conv_fwd_concat_k(gpu, dt, case):
+    """mi355_conv_fwd_cat: heatmap_conv(hm) + feature_conv(x) (reference regda_7.py:4575, :4651-4654) as one implicit GEMM against
+    torch's two convs on the same rounded operands; the fused BatchNorm statistics against the stand-alone statistics pass; two runs
+    bit-identical."""
+    ops = _ops()
+    N, Ci, H, W, Co, k, s, p, K = case
+    x = _round(randn(1, N, Ci, H, W), dt)
+    w = _round(randn(2, Co, Ci, k, k, scale=1.0 / np.sqrt(Ci * k * k)), dt)
+    b1, b2 = randn(3, Co, scale=0.1), randn(4, Co, scale=0.1)
+    y1 = F.conv2d(x, w, b1, stride=s, padding=p)
+    Ho, Wo = y1.shape[2:]
+    hm = _round(randn(5, N, K, Ho, Wo), dt)
+    w2 = _round(randn(6, Co, K, 1, 1, scale=0.2), dt)
+    ref = y1 + F.conv2d(hm, w2, b2)
+    desc = ops.make_desc(N, H, W, Ci, Co, k, k, s, p, DT[dt])
+    xd = _nhwc(x, dt, gpu)
+    wf, _ = ops.pack_weights(w.permute(0, 2, 3, 1).contiguous().to(gpu), Co, k * k, Ci, Ci, DT[dt])
+    w2f, w2t = ops.pack_weights(w2.permute(0, 2, 3, 1).contiguous().to(gpu), Co, 1, K, 32, DT[dt])
+    hm32 = _nhwc(hm, dt, gpu, 32)
+    y = ops.conv_fwd_cat(desc, xd, wf, b1.to(gpu), hm32, w2f.view(Co, 32), b2.to(gpu))
+    assert tuple(y.shape) == tuple(ref.shape)
+    assert float((_back(y) - ref).abs().max()) <= _tol(dt, ref)
+    ys, part = ops.conv_fwd_cat(desc, xd, wf, b1.to(gpu), hm32, w2f.view(Co, 32), b2.to(gpu), want_stats=True)
+    assert torch.equal(ys, y) and part is not None and part[1] >= 1
+    gamma, beta = (1 + 0.1 * randn(23, Co)).to(gpu), (0.1 * randn(24, Co)).to(gpu)
+    outs = []
+    for pp in (None, part):
+        rm, rv = torch.zeros(Co, device=gpu), torch.ones(Co, device=gpu)
+        nbt = torch.zeros((), dtype=torch.int64, device=gpu)
+        outs.append(ops.bn_train_fwd(y, None, gamma, beta, rm, rv, nbt, 1e-5, 0.1, True, partial=pp) + (rm, rv))
+    (ya, ma, ia, rma, rva), (yb, mb, ib, rmb, rvb) = outs
+    assert torch.allclose(ma, mb, rtol=1e-5, atol=1e-6) and torch.allclose(ia, ib, rtol=2e-5, atol=1e-6)
+    assert torch.allclose(rma, rmb, rtol=1e-5, atol=1e-6) and torch.allclose(rva, rvb, rtol=2e-5, atol=1e-6)
+    # no biases, and the error path: a second operand wider than one K tile is refused
+    y0 = ops.conv_fwd_cat(desc, xd, wf, None, hm32, w2f.view(Co, 32), None)
+    assert float((_back(y0) - (ref - b1.view(1, -1, 1, 1) - b2.view(1, -1, 1, 1))).abs().max()) <= _tol(dt, ref)
+    import mi355
+    wide = ops.nhwc_empty(N, 128, Ho, Wo, DT[dt], gpu)
+    with pytest.raises(mi355.Mi355Error):
+        ops.conv_fwd_cat(desc, xd, wf, None, wide, torch.zeros(Co, 128, dtype=DT[dt], device=gpu), None)
+
+
 @pytest.mark.parametrize('dt', ['f32', 'bf16'])
 @pytest.mark.parametrize('shape', [(4, 64, 16, 16), (2, 256, 8, 8), (3, 2048, 4, 4), (2, 24, 5, 7)])
 @pytest.mark.parametrize('relu,res', [(True, False), (True, True), (False, False)])
