@@ -30,10 +30,8 @@ for p in (ROOT, PKG):
 # forward conv+deconv GFLOPs per image (2*MAC), SURVEY.md table A3 / BASELINE.md section 4
 F_GFLOP = {('resnet18', 128): 5.611, ('resnet18', 256): 22.443, ('resnet50', 256): 29.188,
            ('resnet101', 256): 38.885, ('resnet101', 512): 155.540}
-# dense MFMA peaks, MI355X_MICROARCH.md.  'fp8' lines are priced against the chip's dense fp8 peak (5 PFLOP/s) although the path
-# uses the NON-scaled v_mfma_f32_32x32x16_fp8_fp8, which issues at the bf16 rate (the 5 PFLOP/s belong to the block-scaled K=64
-# instruction): the fraction says how far the fp8 configuration is from what the hardware offers, not how well this
-# instruction is fed.
+# dense MFMA peaks, MI355X_MICROARCH.md.  'fp8' lines are priced against the chip's dense fp8 peak (5 PFLOP/s): the fp8 kernels use
+# the K = 64 instruction v_mfma_f32_32x32x64_f8f6f4 (the block-scaled opcode's encoding with unit scales), which issues at that rate.
 PEAK_TFLOPS = {'bf16': 2500.0, 'f32': 157.3, 'fp8': 5000.0}
 
 
@@ -51,6 +49,9 @@ def parse():
     ap.add_argument('--graph', action='store_true', help='replay HIP graphs also with more than one rank (default there: eager; '
                     'at B=64 the iteration is GPU-bound either way: 44.72 ms replayed vs 44.75 ms eager)')
     ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--launch-log', default=None, metavar='PATH', help='after the roofline pass run ONE more eager iteration with every logged '
+                    'kernel family bracketed by events (conv MFMA, BatchNorm, slab reductions) and write the per-launch list as JSON: '
+                    'the input of profiles/insitu_table.py')
     ap.add_argument('--no-eval', action='store_true', help='skip the forward-only (test.py path) section: profiler runs that should see training iterations only')
     ap.add_argument('--cpu-baseline-batch', type=int, default=4)
     ap.add_argument('--cpu-baseline-iters', type=int, default=3)
@@ -116,6 +117,28 @@ def cpu_baseline(arch, image_size, batch, iters):
     return {'value': round(2 * batch / dt, 3), 'unit': 'images/s', 'cores': cores, 'kind': 'port',
             'sample': '%d full A+B+C iterations of %s at %dx%d, batch %d, fp32, %d threads (after 1 warm-up); '
                       '%.2f s/iteration' % (iters, arch, image_size, image_size, batch, cores, dt)}
+
+
+def insitu_top(launches, iters, overhead_us, mfma_tflops, hbm_tbps=6.3, k=10):
+    """Group the conv-family launches of the roofline pass by layer label; per label: launches / iteration, mean in-situ duration
+    (event time minus dispatch latency), floor and gap.  Returns the k largest gaps and the table's total (ms / iteration)."""
+    rows = {}
+    for e in launches:
+        if e['family'] != 0:
+            continue
+        r = rows.setdefault(e['label'], [0, 0.0, e['flops'], e['bytes']])
+        r[0] += 1; r[1] += max(e['us'] - overhead_us, 0.0)
+    out, total = [], 0.0
+    for lab, (n, us, fl, by) in rows.items():
+        mean = us / n
+        floor = max(fl / (mfma_tflops * 1e12) * 1e6, by / (hbm_tbps * 1e12) * 1e6, 5.0)
+        per_it = n / float(iters)
+        total += mean * per_it
+        out.append({'layer': lab, 'per_step': round(per_it, 2), 'us': round(mean, 1), 'floor_us': round(floor, 1),
+                    'gap_ms_per_step': round((mean - floor) * per_it * 1e-3, 3)})
+    out.sort(key=lambda r: -r['gap_ms_per_step'])
+    return {'floor': 'max(FLOP / %.0f TFLOP/s, bytes / %.1f TB/s, 5 us)' % (mfma_tflops, hbm_tbps), 'layers': len(out),
+            'table_ms_per_step': round(total * 1e-3, 3), 'top': out[:k]}
 
 
 def main():
@@ -279,6 +302,17 @@ def main():
                 'mfma_bound': {'launches_per_step': int(sp[7]) // n_prof, 'ms_per_step': round(sp[4] / n_prof, 3),
                                'achieved_TFLOPs': round(sp[5] / (sp[4] * 1e-3) / 1e12, 1), 'peak_TFLOPs': peak,
                                'frac': round(sp[5] / (sp[4] * 1e-3) / 1e12 / peak, 4)}}
+        # in-situ layer table of the family: the launches of the pass above grouped by layer label, each against its own floor
+        # max(FLOP / 1.75 PFLOP/s [the dense bf16 rate at the 1.67 GHz the chip holds under MFMA load], bytes / 6.3 TB/s [achievable
+        # HBM], 5 us); event times minus the calibrated dispatch latency; the ten largest gaps (ms per iteration above the floor)
+        roof['insitu_top'] = insitu_top(ops.prof_launches(), n_prof, roof['event_dispatch_overhead_us'], PEAK_TFLOPS[args.dtype] * 0.7)
+        if args.launch_log and world == 1:
+            ops.prof_reset(); ops.prof_enable(2)
+            ops.spin_us(int(min(1.5 * host_ms + 20.0, 1500.0) * 1e3))
+            step.run(batch); tick()
+            torch.cuda.synchronize()
+            ops.prof_enable(False)
+            json.dump({'event_dispatch_overhead_us': roof['event_dispatch_overhead_us'], 'launches': ops.prof_launches()}, open(args.launch_log, 'w'))
     if world > 1:
         dist.barrier()
 

@@ -6,6 +6,7 @@
 #include "common.h"
 #include "fp8_common.h"
 #include <stdlib.h>
+#include <string>
 
 struct BnPlan { int cpr, TX, TY, colgroups, nslices, rows_per_slice; };
 
@@ -768,11 +769,21 @@ extern "C" int mi355_bn_train_fwd(const void* x, const void* residual, void* y, 
   float* partial = reinterpret_cast<float*>(ws);
   float* ss = partial + (size_t)p.nslices * C * 3;
   dim3 g(p.colgroups, p.nslices);
-  if (dtype == MI355_BF16) hipLaunchKernelGGL(bn_stats_kernel<bf16_t>, g, dim3(256), 0, st, (const bf16_t*)x, partial, rows, C, p.TX, p.rows_per_slice);
-  else hipLaunchKernelGGL(bn_stats_kernel<float>, g, dim3(256), 0, st, (const float*)x, partial, rows, C, p.TX, p.rows_per_slice);
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 4)), dim3(256), 0, st, partial, p.nslices, C, gamma, beta, running_mean, running_var, nbt, save_mean, save_invstd, ss, eps, momentum, stat_updates);
+  const double nb = (double)rows * C * (dtype == MI355_BF16 ? 2.0 : 4.0);
+  char lab[96];
+  if (prof_on()) snprintf(lab, sizeof(lab), "rows%ld C%d%s%s", rows, C, relu ? " relu" : "", residual ? " +res" : "");
+  {
+    ProfScope ps(st, 0.0, nb, 1, prof_on() ? (std::string("bn_stats ") + lab).c_str() : nullptr);
+    if (dtype == MI355_BF16) hipLaunchKernelGGL(bn_stats_kernel<bf16_t>, g, dim3(256), 0, st, (const bf16_t*)x, partial, rows, C, p.TX, p.rows_per_slice);
+    else hipLaunchKernelGGL(bn_stats_kernel<float>, g, dim3(256), 0, st, (const float*)x, partial, rows, C, p.TX, p.rows_per_slice);
+  }
+  {
+    ProfScope ps(st, 0.0, 12.0 * p.nslices * C, 1, prof_on() ? (std::string("bn_finalize ") + lab).c_str() : nullptr);
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 4)), dim3(256), 0, st, partial, p.nslices, C, gamma, beta, running_mean, running_var, nbt, save_mean, save_invstd, ss, eps, momentum, stat_updates);
+  }
   dim3 ga = apply_grid(p, rows);
   const float* nf = nullptr;
+  ProfScope ps(st, 0.0, nb * (residual ? 3 : 2), 1, prof_on() ? (std::string("bn_apply ") + lab).c_str() : nullptr);
   if (q8_out) hipLaunchKernelGGL((bn_apply_kernel<bf16_t, false, true>), ga, dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)residual, (bf16_t*)y, (const float*)ss, nf, nf, nf, nf, eps, rows, C, p.TX, relu, mk, (unsigned char*)q8_out, q8_state);
   else if (dtype == MI355_BF16) hipLaunchKernelGGL((bn_apply_kernel<bf16_t, false>), ga, dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)residual, (bf16_t*)y, (const float*)ss, nf, nf, nf, nf, eps, rows, C, p.TX, relu, mk);
   else hipLaunchKernelGGL((bn_apply_kernel<float, false>), ga, dim3(256), 0, st, (const float*)x, (const float*)residual, (float*)y, (const float*)ss, nf, nf, nf, nf, eps, rows, C, p.TX, relu, mk);
@@ -795,10 +806,17 @@ extern "C" int mi355_bn_train_fwd_partials(const void* x, const void* residual, 
   hipStream_t st = as_stream(stream);
   BnPlan p = bn_plan(rows, C, CH);
   static const int wide_min = getenv("MI355_BN_WIDE_FINALIZE") ? atoi(getenv("MI355_BN_WIDE_FINALIZE")) : 512;
-  if (nslices >= wide_min) hipLaunchKernelGGL(bn_finalize_wide_kernel, dim3(C), dim3(256), 0, st, partial, nslices, C, gamma, beta, running_mean, running_var, nbt, save_mean, save_invstd, scale_shift, eps, momentum, stat_updates);
-  else hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 4)), dim3(256), 0, st, partial, nslices, C, gamma, beta, running_mean, running_var, nbt, save_mean, save_invstd, scale_shift, eps, momentum, stat_updates);
+  const double nb = (double)rows * C * (dtype == MI355_BF16 ? 2.0 : 4.0);
+  char lab[96];
+  if (prof_on()) snprintf(lab, sizeof(lab), "rows%ld C%d ns%d%s%s", rows, C, nslices, relu ? " relu" : "", residual ? " +res" : "");
+  {
+    ProfScope ps(st, 0.0, 12.0 * nslices * C, 1, prof_on() ? (std::string("bn_finalize ") + lab).c_str() : nullptr);
+    if (nslices >= wide_min) hipLaunchKernelGGL(bn_finalize_wide_kernel, dim3(C), dim3(256), 0, st, partial, nslices, C, gamma, beta, running_mean, running_var, nbt, save_mean, save_invstd, scale_shift, eps, momentum, stat_updates);
+    else hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 4)), dim3(256), 0, st, partial, nslices, C, gamma, beta, running_mean, running_var, nbt, save_mean, save_invstd, scale_shift, eps, momentum, stat_updates);
+  }
   dim3 ga = apply_grid(p, rows);
   const float* nf = nullptr;
+  ProfScope ps(st, 0.0, nb * (residual ? 3 : 2), 1, prof_on() ? (std::string("bn_apply ") + lab).c_str() : nullptr);
   if (q8_out) hipLaunchKernelGGL((bn_apply_kernel<bf16_t, false, true>), ga, dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)residual, (bf16_t*)y, (const float*)scale_shift, nf, nf, nf, nf, eps, rows, C, p.TX, relu, mk, (unsigned char*)q8_out, q8_state);
   else if (dtype == MI355_BF16) hipLaunchKernelGGL((bn_apply_kernel<bf16_t, false>), ga, dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)residual, (bf16_t*)y, (const float*)scale_shift, nf, nf, nf, nf, eps, rows, C, p.TX, relu, mk);
   else hipLaunchKernelGGL((bn_apply_kernel<float, false>), ga, dim3(256), 0, st, (const float*)x, (const float*)residual, (float*)y, (const float*)scale_shift, nf, nf, nf, nf, eps, rows, C, p.TX, relu, mk);
@@ -819,11 +837,17 @@ extern "C" int mi355_bn_relu_maxpool_fwd_partials(const void* x, void* y_pool, u
   if (!partial || nslices < 1 || !scale_shift || !argidx || !y_pool) MI_FAIL(MI355_EINVAL, "bn_relu_maxpool_fwd_partials: null argument");
   hipStream_t st = as_stream(stream);
   static const int wide_min = getenv("MI355_BN_WIDE_FINALIZE") ? atoi(getenv("MI355_BN_WIDE_FINALIZE")) : 512;
-  if (nslices >= wide_min) hipLaunchKernelGGL(bn_finalize_wide_kernel, dim3(C), dim3(256), 0, st, partial, nslices, C, gamma, beta, running_mean, running_var, nbt, save_mean, save_invstd, scale_shift, eps, momentum, stat_updates);
-  else hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 4)), dim3(256), 0, st, partial, nslices, C, gamma, beta, running_mean, running_var, nbt, save_mean, save_invstd, scale_shift, eps, momentum, stat_updates);
+  char lab[96];
+  if (prof_on()) snprintf(lab, sizeof(lab), "rows%ld C%d ns%d", rows, C, nslices);
+  {
+    ProfScope ps(st, 0.0, 12.0 * nslices * C, 1, prof_on() ? (std::string("bn_finalize ") + lab).c_str() : nullptr);
+    if (nslices >= wide_min) hipLaunchKernelGGL(bn_finalize_wide_kernel, dim3(C), dim3(256), 0, st, partial, nslices, C, gamma, beta, running_mean, running_var, nbt, save_mean, save_invstd, scale_shift, eps, momentum, stat_updates);
+    else hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 4)), dim3(256), 0, st, partial, nslices, C, gamma, beta, running_mean, running_var, nbt, save_mean, save_invstd, scale_shift, eps, momentum, stat_updates);
+  }
   const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
   const long total = (long)N * Ho * Wo * (C / CH);
   int grid = (int)((total + 255) / 256); if (grid > 8192) grid = 8192;
+  ProfScope ps(st, 0.0, (double)rows * C * (dtype == MI355_BF16 ? 2.0 : 4.0) * 1.25, 1, prof_on() ? (std::string("bn_relu_maxpool ") + lab).c_str() : nullptr);
   if (dtype == MI355_BF16) hipLaunchKernelGGL(bn_relu_maxpool_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, (const bf16_t*)x, (const float*)scale_shift, (bf16_t*)y_pool, argidx, N, H, W, C, Ho, Wo);
   else hipLaunchKernelGGL(bn_relu_maxpool_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)x, (const float*)scale_shift, (float*)y_pool, argidx, N, H, W, C, Ho, Wo);
   MI_CHECK_LAUNCH("bn_relu_maxpool_fwd_partials");
@@ -963,6 +987,9 @@ extern "C" int mi355_bn_bwd(const void* dy, const void* x, const void* y, const 
     a.G = rp.G; a.R = rp.R; a.rpb = rp.rpb; a.keep = rp.keep; a.accumulate = accumulate; a.inv_rows = 1.0f / (float)rows;
     a.spin_limit = g_bn_res_spin;
     int e;
+    char lab[112];
+    if (prof_on()) snprintf(lab, sizeof(lab), "bn_bwd_res rows%ld C%d relu%d%s keep%d/%d", rows, C, relu, dresidual ? " +dres" : "", rp.keep, rp.rpb);
+    ProfScope ps(st, 0.0, (double)rows * C * (dtype == MI355_BF16 ? 2.0 : 4.0) * (dresidual ? 4 : 3), 1, prof_on() ? lab : nullptr);
     if (dtype == MI355_BF16) e = relu == 0 ? bn_resident_launch<bf16_t, 0>(a, rp.lds, rp.max_lds, st) : relu == 2 ? bn_resident_launch<bf16_t, 2>(a, rp.lds, rp.max_lds, st) : bn_resident_launch<bf16_t, 3>(a, rp.lds, rp.max_lds, st);
     else e = relu == 0 ? bn_resident_launch<float, 0>(a, rp.lds, rp.max_lds, st) : relu == 2 ? bn_resident_launch<float, 2>(a, rp.lds, rp.max_lds, st) : bn_resident_launch<float, 3>(a, rp.lds, rp.max_lds, st);
     if (e == MI355_OK) { MI_CHECK_LAUNCH("bn_bwd (resident)"); return MI355_OK; }
@@ -974,12 +1001,22 @@ extern "C" int mi355_bn_bwd(const void* dy, const void* x, const void* y, const 
   dim3 g(p.colgroups, p.nslices);
 #define MI_RED(T, R) hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, true, R>), g, dim3(256), 0, st, (const T*)dy, (const T*)x, (const T*)y, save_mean, save_invstd, gamma, beta, partial, rows, C, p.TX, p.rows_per_slice, mk)
 #define MI_RED4(T) do { if (relu == 0) MI_RED(T, 0); else if (relu == 1) MI_RED(T, 1); else if (relu == 2) MI_RED(T, 2); else MI_RED(T, 3); } while (0)
-  if (dtype == MI355_BF16) MI_RED4(bf16_t); else MI_RED4(float);
+  const double nb = (double)rows * C * (dtype == MI355_BF16 ? 2.0 : 4.0);
+  char lab[96];
+  if (prof_on()) snprintf(lab, sizeof(lab), "rows%ld C%d relu%d%s", rows, C, relu, dresidual ? " +dres" : "");
+  {
+    ProfScope ps(st, 0.0, nb * 2, 1, prof_on() ? (std::string("bn_bwd_reduce ") + lab).c_str() : nullptr);
+    if (dtype == MI355_BF16) MI_RED4(bf16_t); else MI_RED4(float);
+  }
 #undef MI_RED4
 #undef MI_RED
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 4)), dim3(256), 0, st, partial, p.nslices, C, 1.0f / (float)rows, gamma, save_invstd, dgamma, dbeta, accumulate, coeff);
+  {
+    ProfScope ps(st, 0.0, 12.0 * p.nslices * C, 1, prof_on() ? (std::string("bn_bwd_finalize ") + lab).c_str() : nullptr);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 4)), dim3(256), 0, st, partial, p.nslices, C, 1.0f / (float)rows, gamma, save_invstd, dgamma, dbeta, accumulate, coeff);
+  }
   dim3 ga = apply_grid(p, rows, true);
   if (int e = q8_check(q8_out, q8_state, dtype, C)) return e;
+  ProfScope ps(st, 0.0, nb * (dresidual ? 4 : 3), 1, prof_on() ? (std::string("bn_bwd_apply ") + lab).c_str() : nullptr);
   launch_bwd_apply(dtype, relu, ga, st, dy, x, y, save_mean, save_invstd, coeff, beta, dx, dresidual, rows, C, p.TX, mk, q8_out, q8_state);
   MI_CHECK_LAUNCH("bn_bwd");
   return MI355_OK;

@@ -115,8 +115,15 @@ __device__ inline unsigned fd_div(unsigned n, const FastDiv& f) {
 }
 
 // ---- profiling (conv family) -----------------------------------------------------------
+// family 0 = the MFMA implicit-GEMM conv kernels (what mi355_prof_read / _read_split sum: bench.py's roofline figure),
+// family 1 = BatchNorm kernels, 2 = everything else that is logged.  Each scope brackets exactly ONE kernel launch; its label is
+// the explicit one or, when that is null, the thread's pending tag (prof_set_tag: "fwd k3s1 256>256 @64x64 n64" ...), so that the
+// launches of one iteration can be listed layer by layer (mi355_prof_read_launch) and joined, in launch order, with a rocprofv3
+// kernel trace of the same iteration (profiles/insitu_table.py).
 struct ProfScope {
   hipStream_t s; bool on; int slot;
-  ProfScope(hipStream_t st, double flops, double bytes = 0.0);
+  ProfScope(hipStream_t st, double flops, double bytes = 0.0, int family = 0, const char* label = nullptr);
   ~ProfScope();
 };
+bool prof_on();
+void prof_set_tag(const char* fmt, ...);

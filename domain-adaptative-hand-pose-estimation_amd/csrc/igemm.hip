@@ -1155,6 +1155,9 @@ void launch_slab_reduce(const float* ws, float* dw, long n, int S, long stride, 
   while (SL < 16 && n4 * SL < 65536 && SL * 2 <= S) SL *= 2;
   const int cols = 256 / SL;
   dim3 grid(cdiv(n4, cols));
+  char lab[64];
+  if (prof_on()) snprintf(lab, sizeof(lab), "slab_reduce n%ld S%d", n, S);
+  ProfScope ps(st, 0.0, 4.0 * n * (S + 1), 2, prof_on() ? lab : nullptr);
   if (SL == 1) hipLaunchKernelGGL(slab_reduce_kernel<1>, grid, dim3(256), 0, st, ws, dw, n, S, stride, accumulate);
   else if (SL == 2) hipLaunchKernelGGL(slab_reduce_kernel<2>, grid, dim3(256), 0, st, ws, dw, n, S, stride, accumulate);
   else if (SL == 4) hipLaunchKernelGGL(slab_reduce_kernel<4>, grid, dim3(256), 0, st, ws, dw, n, S, stride, accumulate);
@@ -1249,7 +1252,11 @@ static int dispatch_gather(GatherArgs& a, hipStream_t st) {
       MI_FAIL(MI355_EINVAL, "concat-K forward: plain single-phase forward conv with >= 8 input chunks only");
     if (a.c2 < CH || a.c2 % CH || a.c2 > MmaTraits<T>::BK) MI_FAIL(MI355_EINVAL, "concat-K forward: c2=%d must be a multiple of %d and <= %d", a.c2, CH, MmaTraits<T>::BK);
     const long t128 = cdiv(Mtot, 128L) * cdiv(a.Nout, 128);
-    if (a.Nout <= 64) launch_gather<T, 64, 64, false, 2, 2, false, false, false, true>(a, st);
+    static const int cat_tile = getenv("MI355_CAT_TILE") ? atoi(getenv("MI355_CAT_TILE")) : 0;     // experiment switch
+    if (cat_tile == 1 && a.Nout > 64) launch_gather<T, 128, 128, false, 2, 2, false, false, false, true>(a, st);
+    else if (cat_tile == 2 && a.Nout > 64) launch_gather<T, 128, 128, false, 2, 2, false, true, false, true>(a, st);
+    else if (cat_tile == 3 && a.Nout > 64) launch_gather<T, 64, 128, false, 2, 2, false, false, false, true>(a, st);
+    else if (a.Nout <= 64) launch_gather<T, 64, 64, false, 2, 2, false, false, false, true>(a, st);
     else if ((dma_mode == 2) || (dma_mode == 1 && ((t128 >= 512 && kavg >= 128) || (t128 >= 256 && kavg >= 256)))) launch_gather<T, 128, 128, false, 2, 2, false, true, false, true>(a, st);
     else if (t128 >= 512 && kavg <= 32 && sizeof(T) == 2) launch_gather<T, 64, 128, false, 2, 2, false, false, false, true>(a, st);
     else if (t128 >= 512) launch_gather<T, 128, 128, false, 2, 2, false, false, false, true>(a, st);
@@ -1340,6 +1347,8 @@ static int conv_fwd_impl(const mi355_conv_desc* d, const void* x, const void* w,
   if ((d->dtype == MI355_FP8) != (f8 != nullptr)) MI_FAIL(MI355_EINVAL, "fp8 descriptors go through the *_fp8 entry points (and only they)");
   if (relu && (bn || f8 || partial)) MI_FAIL(MI355_EINVAL, "conv_fwd: the fused ReLU is an inference epilogue (no statistics / BatchNorm-backward / fp8 variant)");
   GatherArgs a; memset(&a, 0, sizeof(a));
+  if (prof_on()) prof_set_tag("fwd%s k%ds%d %d>%d @%dx%d n%d%s%s%s", f8 ? "8" : "", d->kh, d->stride, d->Ci, d->Co, d->Hi, d->Wi, d->N, partial ? " +stats" : "",
+                              residual ? " +res" : "", cat ? " +cat" : "");
   a.relu = relu ? 1 : 0;
   a.A = x; a.B = w; a.D = y; a.bias = bias; a.residual = residual; a.scale = nullptr;
   a.Hi = d->Hi; a.Wi = d->Wi; a.Ci = d->Ci; a.in_sy = a.in_sx = d->stride;
@@ -1420,6 +1429,7 @@ static int heatmap_conv(const void* x, const void* w, const float* bias, float* 
   if (a.cshift < 3) MI_FAIL(MI355_EINVAL, "conv1x1_heatmap: C/%d must be a power of two >= 8 (C=%d)", CH, C);
   a.a_bytes = (unsigned)((long)N * HW * C * (long)sizeof(T));
   a.b_bytes = (unsigned)((long)K * C * (long)sizeof(T));
+  if (prof_on()) prof_set_tag("hm1x1 %d>%d hw%d n%d", C, K, HW, N);
   ProfScope ps(st, 2.0 * N * HW * (double)K * C, (double)a.a_bytes + a.b_bytes + 4.0 * N * HW * K);
   launch_gather<T, 128, 32, false, 4, 1, true>(a, st);
   MI_CHECK_LAUNCH("conv1x1_heatmap");
@@ -1504,6 +1514,8 @@ static int conv_dgrad_impl(const mi355_conv_desc* d, const void* dy, const void*
     MI_CHECK_LAUNCH("zero_fill");
   }
   GatherArgs a; memset(&a, 0, sizeof(a));
+  if (prof_on()) prof_set_tag("dgrad%s k%ds%d %d>%d @%dx%d n%d%s%s%s", f8 ? "8" : "", d->kh, d->stride, d->Ci, d->Co, d->Hi, d->Wi, d->N, partial ? " +stats" : "",
+                              accumulate ? (acc_mask ? " +macc" : " +acc") : "", bn ? " +bnb" : "");
   a.A = dy; a.B = wT; a.D = dx; a.bias = bias; a.residual = nullptr; a.scale = scale_dev;
   a.Hi = d->Ho; a.Wi = d->Wo; a.Ci = d->Co;
   a.in_sy = a.in_sx = 1; a.Ho = d->Hi; a.Wo = d->Wi; a.out_sy = a.out_sx = s;
@@ -1617,6 +1629,7 @@ extern "C" int mi355_conv_wgrad(const mi355_conv_desc* d, const void* x, const v
     k.x_bytes = (unsigned)((long)d->N * d->Hi * d->Wi * d->Ci * 2); k.dy_bytes = (unsigned)((long)k.M * d->Co * 2);
     k.dHo = make_fastdiv(d->Ho);
     {
+      if (prof_on()) prof_set_tag("wgrad_kw2 k%ds%d %d>%d @%dx%d n%d S%d", d->kh, d->stride, d->Ci, d->Co, d->Hi, d->Wi, d->N, w.S);
       ProfScope ps(st, 2.0 * k.M * (double)d->Co * w.ldw, (double)k.x_bytes + (double)k.dy_bytes + 4.0 * d->Co * w.ldw);
       dim3 grid(w.nto * d->kh * w.nti * w.S);
       if (d->kh == 3) { if (w.mt == 1) hipLaunchKernelGGL((wgrad_kw2_kernel<1, 3>), grid, dim3(256), 0, st, k); else hipLaunchKernelGGL((wgrad_kw2_kernel<2, 3>), grid, dim3(256), 0, st, k); }
@@ -1636,6 +1649,7 @@ extern "C" int mi355_conv_wgrad(const mi355_conv_desc* d, const void* x, const v
     k.x_bytes = (unsigned)((long)d->N * d->Hi * d->Wi * d->Ci * 2); k.dy_bytes = (unsigned)((long)k.M * d->Co * 2);
     k.dH = make_fastdiv(d->Hi);
     {
+      if (prof_on()) prof_set_tag("wgrad_kw k%ds%d %d>%d @%dx%d n%d S%d", d->kh, d->stride, d->Ci, d->Co, d->Hi, d->Wi, d->N, w.S);
       ProfScope ps(st, 2.0 * k.M * (double)d->Co * w.ldw, (double)k.x_bytes + (double)k.dy_bytes + 4.0 * d->Co * w.ldw);
       dim3 grid(w.nto * 3 * w.nti * w.S);
       if (w.mt == 1) hipLaunchKernelGGL(wgrad_kw_kernel<1>, grid, dim3(256), 0, st, k);
@@ -1658,6 +1672,7 @@ extern "C" int mi355_conv_wgrad(const mi355_conv_desc* d, const void* x, const v
   a.dWo = make_fastdiv(d->Wo); a.dHo = make_fastdiv(d->Ho);
   { const long esz = d->dtype == MI355_BF16 ? 2 : 4; a.x_bytes = (unsigned)((long)d->N * d->Hi * d->Wi * d->Ci * esz); a.dy_bytes = (unsigned)((long)a.M * d->Co * esz); }
   {
+    if (prof_on()) prof_set_tag("wgrad k%ds%d %d>%d @%dx%d n%d S%d", d->kh, d->stride, d->Ci, d->Co, d->Hi, d->Wi, d->N, w.S);
     ProfScope ps(st, 2.0 * a.M * (double)d->Co * w.ldw, (double)a.x_bytes + (double)a.dy_bytes + 4.0 * d->Co * w.ldw);
     dim3 grid(w.nto * w.nti * w.S);
     if (d->dtype == MI355_BF16) hipLaunchKernelGGL(wgrad_gemm_kernel<bf16_t>, grid, dim3(256), 0, st, a);
@@ -1765,12 +1780,22 @@ static int launch_wgrad_group(const mi355_wgrad_item* items, const int* idx, int
   {
     double flops = 0, bytes = 0;
     for (int k = 0; k < n; ++k) { const WgradArgs& a = g.p[k]; flops += 2.0 * a.M * (double)a.Co * a.ldw; bytes += (double)a.x_bytes + a.dy_bytes + 4.0 * a.Co * a.ldw; }
+    if (prof_on()) {
+      const mi355_conv_desc* d0 = &items[idx[0]].d;
+      prof_set_tag("wgrad_group x%d blocks%d first k%ds%d %d>%d @%dx%d", n, nb, d0->kh, d0->stride, d0->Ci, d0->Co, d0->Hi, d0->Wi);
+    }
     ProfScope ps(st, flops, bytes);
     if (items[idx[0]].d.dtype == MI355_BF16) hipLaunchKernelGGL(wgrad_group_kernel<bf16_t>, dim3(nb), dim3(256), 0, st, g);
     else hipLaunchKernelGGL(wgrad_group_kernel<float>, dim3(nb), dim3(256), 0, st, g);
     MI_CHECK_LAUNCH("wgrad_group");
   }
-  if (sg.n) { hipLaunchKernelGGL(slab_reduce_group_kernel, dim3(nsb), dim3(256), 0, st, sg); MI_CHECK_LAUNCH("slab_reduce_group"); }
+  if (sg.n) {
+    double sb = 0; for (int k = 0; k < sg.n; ++k) sb += 16.0 * sg.it[k].n4 * (sg.it[k].S + 1);
+    char lab[64];
+    if (prof_on()) snprintf(lab, sizeof(lab), "slab_reduce_group x%d", sg.n);
+    ProfScope ps(st, 0.0, sb, 2, prof_on() ? lab : nullptr);
+    hipLaunchKernelGGL(slab_reduce_group_kernel, dim3(nsb), dim3(256), 0, st, sg); MI_CHECK_LAUNCH("slab_reduce_group");
+  }
   return MI355_OK;
 }
 extern "C" int mi355_conv_wgrad_grouped(const mi355_wgrad_item* items, int n, void* ws, size_t ws_bytes, void* stream) {

@@ -1,39 +1,37 @@
-// Persistent pipelined GEMM for the 1x1 / unit-stride convolutions (forward and input gradient), bf16, gfx950.
+// Weights-stationary streaming GEMM for the 1x1 / unit-stride convolutions (forward and input gradient), bf16, gfx950.
 //
 //   D[m][n] = epilogue( sum_k A[m][k] * B[n][k] )      A: [M][K] activations (NHWC rows ARE the GEMM rows: no gather),
 //                                                      B: [N][K] packed weights, K = channels (multiple of 64)
 //
-// A second kernel beside gather_gemm_kernel (igemm.hip), OFF by default (MI355_PGEMM / mi355_set_pgemm).  Timed per layer in
-// isolation (graph replay, operands warm in L2 / Infinity Cache) it is 15 - 30 % faster on the K-heavy layers with M <= 16 K rows
-// and on narrow outputs, and slower where the BatchNorm-statistics epilogue dominates (profiles/r03_pgemm_phases.txt); inside the
-// training iteration and the inference forward, where operands arrive from HBM, it gains nothing: 33.31 vs 33.22 / 33.40 ms with
-// the selective policy (mode 1), 33.21 vs 32.65 ms and 20.5 k vs 21.5 k images/s when it takes every launch it fits (mode 2).  It
-// stays in the tree as the measured answer to "a persistent / weights-stationary kernel for the 1x1 convs", with its parity
-// tests (tests/test_gpu_kernels.py: identical bits to the gather kernel), not on the product path.  What it does:
-//   * the operands are plain row-major matrices, so a K step's global addresses are ONE per-lane offset per 1-KiB piece, fixed
-//     for the whole tile, plus a scalar (k * 128 bytes) in the instruction's soffset: no per-step vector arithmetic;
-//   * tiles travel global -> LDS by LDS-DMA (buffer_load ... lds) into a ring of NS stages with NS-1 K steps in flight (counted
-//     vmcnt), ONE barrier per K step (a raw s_barrier: the fences of __syncthreads() would drain the ring), no staging
-//     registers, no ds_write; a K step's fragment reads and MFMAs are one hand-scheduled asm statement;
-//   * the kernel is PERSISTENT: a block walks a list of tiles and the ring never drains -- the first K steps of the next tile are
-//     in flight while the current tile's epilogue streams out (staged in the ring slot its last K step has just freed);
-//   * same epilogue menu as the gather kernel: bias, device scalar (gradient-layer lambda), residual, accumulate (+ bit mask),
-//     ReLU (inference), BatchNorm statistics of the output (EPI = 1: kept for completeness and tests, not dispatched by default).
-// What was tried beyond this form and measured slower (wave-specialised MFMA / epilogue / loader roles on a static per-K-step
-// barrier schedule) is in profiles/r03_pgemm_phases.txt together with the in-kernel stamps that explain why: with 64 - 96 KB of
-// ring per CU the operand fill (~30 B/clk per CU, whichever waves issue it) bounds these layers, not the schedule.
+// The 1x1 convs at 64x64 / 32x32 maps are HBM-bound (a few hundred FLOP per byte at most), yet the gather kernel runs them at
+// 2.5 TB/s: with 64x128 / 128x128 output tiles every tile re-stages its slice of the weights, so two thirds of the bytes that
+// enter a CU's LDS are weights (256 -> 256 @64x64, B = 64: 786 MB through the CUs' vector-memory path for 268 MB of HBM
+// traffic), and that path takes in ~30 B/clk per CU whichever waves issue the loads (profiles/r03_pgemm_phases.txt) -- the
+// launch is bound by LDS fill, not by HBM.  Round 3's persistent ring kernel streamed both operands through its ring and hit
+// the same wall.  This kernel keeps the block's WEIGHT SLICE RESIDENT in LDS instead:
+//   * a persistent block owns ONE column tile (BN output channels) for its whole life: its [BN][K] weight slice is fetched once
+//     (K * BN * 2 bytes <= 64 KB) and stays; the block then walks the row tiles gm, gm + Gm, ... of that column tile;
+//   * only activations stream: an LDS-DMA ring of NS stages of BM x 64 channels (buffer_load ... lds, swizzle applied on the
+//     source address), NS - 1 K steps in flight across tile boundaries (counted vmcnt), ONE raw s_barrier per K step; the bytes
+//     entering LDS per output tile drop to the activation tile itself = the HBM bytes;
+//   * the epilogue stages the tile in a region of its own (the ring never drains: the next tiles' activations are in flight
+//     while a tile's epilogue streams out); same epilogue menu as the gather kernel -- bias, device scalar (gradient-layer
+//     lambda), residual, accumulate (+ bit mask), ReLU (inference), BatchNorm statistics of the output (EPI = 1);
+//   * a K step's fragment reads and MFMAs are one hand-scheduled asm statement (hipcc sank the MFMAs below the waits and
+//     shuttled the accumulators between the register files around the conditional epilogue).
 // Fragment layout, LDS row swizzle and MFMA operand order are those of gather_gemm_kernel (128-byte rows, chunk ^ (row >> 1) & 7,
-// D^T accumulators); both kernels produce the same bits for the same element.
+// D^T accumulators); both kernels produce the same bits for the same element (tests/test_gpu_kernels.py).
 #include "common.h"
 #include <stdlib.h>
 
 #include "igemm_common.h"
 
+// LDS of a block: [weight slice: nk K steps x BN rows x 128 B][ring: NS stages x BM rows x 128 B][output staging: BM x BN bf16]
 template <int BM, int BN, int NS>
 struct PgSmem {
-  static constexpr int kStage = (BM + BN) * 128;
-  static constexpr int kBytes = NS * kStage;
-  static_assert(BM * BN * 2 <= kStage, "the epilogue stages the output tile in one ring slot");
+  static constexpr int kStage = BM * 128;
+  static constexpr int kOut = BM * BN * 2;
+  static constexpr int bytes(int nk) { return nk * BN * 128 + NS * kStage + kOut; }
 };
 
 // swizzled byte offset of 16-byte chunk c of output-tile row r in the epilogue staging image (rows of BN * 2 bytes, no padding):
@@ -61,7 +59,16 @@ __device__ __forceinline__ float lds_read4(unsigned a) { float v; asm volatile("
 // by hand (lgkmcnt / counted vmcnt) before the barrier that publishes it; nothing is handed over through global memory.
 #define RAW_BARRIER() asm volatile("s_barrier" ::: "memory")
 
-template <int BM, int BN, int NS, int EPI>
+template <int N> __device__ __forceinline__ void wait_vm() {
+  static_assert(N >= 0, "vmcnt immediate");
+  asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N > 63 ? 63 : N) : "memory");
+}
+
+// ADD: the build whose epilogue reads global memory (residual / the gradient accumulated onto / its bit mask).  A build of its own:
+// a wave consumes its vector-memory results in issue order, so an epilogue load can only be used once every ring stage issued
+// before it has landed, and hipcc guards the load's destination registers with vmcnt(0) in the K loop even when the branch is not
+// taken -- the plain builds must not contain such loads at all.
+template <int BM, int BN, int NS, int EPI, bool ADD>
 __global__ __launch_bounds__(256) void pgemm_kernel(const GatherArgs p) {
   constexpr int CH = 8, NTHR = 256;
   constexpr int WM = BM / 2, WN = BN / 2, MT = WM / 32, NT = WN / 32;
@@ -81,42 +88,53 @@ __global__ __launch_bounds__(256) void pgemm_kernel(const GatherArgs p) {
   const int lc = t & 7, lr = t >> 3;
   const int lcs = lc ^ ((lr >> 1) & 7);                      // the swizzle is applied on the SOURCE address
   const int r31 = lane & 31, hi = lane >> 5;
-  const int M = p.ph[0].M, K = p.Ci, nk = K >> 6, ntn = p.ntn;
-  const int G = (int)gridDim.x;
-  const int pos = xcd_remap((int)blockIdx.x, G);             // blocks of one XCD take neighbouring tiles (same A rows)
-  const int my_tiles = pos < p.ntiles ? (p.ntiles - pos + G - 1) / G : 0;
+  const int M = p.ph[0].M, K = p.Ci, nk = K >> 6, ntn = p.ntn, ntm = p.ph[0].ntm;
+  const int G = (int)gridDim.x, Gm = G / ntn;                // (host: G is a multiple of ntn)
+  const int pos = xcd_remap((int)blockIdx.x, G);             // blocks of one XCD take neighbouring (row group, column tile) pairs: same A rows
+  const int tn = pos % ntn, gm = pos / ntn;                  // this block's column tile, and its first row tile
+  const int my_tiles = gm < ntm ? (ntm - gm + Gm - 1) / Gm : 0;
   const int total = my_tiles * nk;
   if (total == 0) return;
+  const unsigned ring_base = smem_base + (unsigned)(nk * BN * 128), out_base = ring_base + (unsigned)(NS * SM::kStage);
 
   const __amdgpu_buffer_rsrc_t rsA = make_rsrc(p.A, p.a_bytes), rsB = make_rsrc(p.B, p.b_bytes);
   (void)rsA; (void)rsB;                                      // (only used in the device pass)
 
   // ---- issue side: tile / K step of the next LDS-DMA stage to launch
-  int is_tile = 0, is_kt = 0, is_gs = 0;
-  int voffA[PA], voffB[PB];
+  int is_tile = 0, is_kt = 0, is_gs = 0, is_slot = 0;
+  int voffA[PA];
   auto set_issue_tile = [&](int i) {
-    const int lin = i * G + pos, tm = lin / ntn, tn = lin - tm * ntn;
+    const int tm = gm + i * Gm;
 #pragma unroll
     for (int j = 0; j < PA; ++j) { const int m = tm * BM + j * 32 + lr; voffA[j] = m < M ? (m * K + lcs * CH) * 2 : OOB_OFF; }
-#pragma unroll
-    for (int j = 0; j < PB; ++j) { const int n = tn * BN + j * 32 + lr; voffB[j] = n < p.Nout ? (n * p.ldb + lcs * CH) * 2 : OOB_OFF; }
   };
   auto issue = [&]() {                                       // stage is_gs -> ring slot is_gs % NS
-    const int slot = is_gs % NS;
     const int soff = is_kt * 128;
-    (void)slot; (void)soff; (void)wave_u;
+    (void)soff; (void)wave_u;
 #if defined(__HIP_DEVICE_COMPILE__)
     typedef __attribute__((address_space(3))) void* ldsp;
-    char* sa = smem + slot * SM::kStage + wave_u * 1024;
-    char* sb = sa + BM * 128;
+    char* sa = smem + nk * BN * 128 + is_slot * SM::kStage + wave_u * 1024;
 #pragma unroll
     for (int j = 0; j < PA; ++j) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (ldsp)(sa + j * 4096), 16, voffA[j], soff, 0, 0);
-#pragma unroll
-    for (int j = 0; j < PB; ++j) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (ldsp)(sb + j * 4096), 16, voffB[j], soff, 0, 0);
 #endif
     ++is_gs;
+    if (++is_slot == NS) is_slot = 0;
     if (++is_kt == nk) { is_kt = 0; ++is_tile; if (is_tile < my_tiles) set_issue_tile(is_tile); }
   };
+  // the block's weight slice, once: K step kt of rows tn * BN .. + BN -> [kt][BN][128 B], same swizzled image as a ring stage
+  {
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef __attribute__((address_space(3))) void* ldsp;
+    int voffB[PB];
+#pragma unroll
+    for (int j = 0; j < PB; ++j) { const int n = tn * BN + j * 32 + lr; voffB[j] = n < p.Nout ? (n * p.ldb + lcs * CH) * 2 : OOB_OFF; }
+    for (int kt = 0; kt < nk; ++kt) {
+      char* sb = smem + kt * BN * 128 + wave_u * 1024;
+#pragma unroll
+      for (int j = 0; j < PB; ++j) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (ldsp)(sb + j * 4096), 16, voffB[j], kt * 128, 0, 0);
+    }
+#endif
+  }
 
   f32x16_t acc[MT][NT];
 #pragma unroll
@@ -132,7 +150,7 @@ __global__ __launch_bounds__(256) void pgemm_kernel(const GatherArgs p) {
 #pragma unroll
     for (int i = 0; i < MT; ++i) fa[i][s] = (unsigned)swz128(wm0 + i * 32 + r31, 2 * s + hi);
 #pragma unroll
-    for (int j = 0; j < NT; ++j) fb[j][s] = (unsigned)(BM * 128 + swz128(wn0 + j * 32 + r31, 2 * s + hi));
+    for (int j = 0; j < NT; ++j) fb[j][s] = (unsigned)swz128(wn0 + j * 32 + r31, 2 * s + hi);
   }
   // One K step = ONE asm statement: 4 x (MT + NT) fragment reads, software-pipelined one 16-deep sub-step ahead of the 4 x MT x NT
   // MFMAs (two fragment buffers), waits counted in lgkmcnt.  hipcc would sink the MFMAs below the later waits and shuttle the
@@ -140,14 +158,14 @@ __global__ __launch_bounds__(256) void pgemm_kernel(const GatherArgs p) {
 #define PG_MFMA(ACC, B, A) "v_mfma_f32_32x32x16_bf16 " ACC ", " B ", " A ", " ACC "\n"
 #define PG_MFMAZ(ACC, B, A) "v_mfma_f32_32x32x16_bf16 " ACC ", " B ", " A ", 0\n"
 #define PG_RD(DST, ADDR) "ds_read_b128 " DST ", " ADDR "\n"
-  auto compute = [&](unsigned stage_addr, int first) {      // first: the tile's first K step (its first MFMAs take C = 0)
+  auto compute = [&](unsigned stage_addr, unsigned w_addr, int first) {      // first: the tile's first K step (its first MFMAs take C = 0)
     unsigned xa[MT][4], xb[NT][4];
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
 #pragma unroll
       for (int i = 0; i < MT; ++i) xa[i][s] = stage_addr + fa[i][s];
 #pragma unroll
-      for (int j = 0; j < NT; ++j) xb[j][s] = stage_addr + fb[j][s];
+      for (int j = 0; j < NT; ++j) xb[j][s] = w_addr + fb[j][s];
     }
     if constexpr (MT == 2 && NT == 2) {
       bf16x8_t a0, a1, b0, b1, c0, c1, d0, d1;      // buffer 0: a0 a1 (A rows) b0 b1 (B rows); buffer 1: c0 c1 / d0 d1
@@ -256,13 +274,49 @@ __global__ __launch_bounds__(256) void pgemm_kernel(const GatherArgs p) {
   const bool affine = p.bias != nullptr || p.scale != nullptr;
   bf16_t* __restrict__ D = reinterpret_cast<bf16_t*>(p.D);
   const bf16_t* __restrict__ R = reinterpret_cast<const bf16_t*>(p.residual);
-  const bool plain = !R && !p.accumulate && !p.relu;         // the staged words go out as they are
+  const bool plain = (!ADD || (!R && !p.accumulate)) && !p.relu;         // the staged words go out as they are
   const int ec = t % CPR, er0 = t / CPR;                     // this thread's chunk column (fixed: 256 % CPR == 0) and first row
   const unsigned rd0 = (unsigned)out_swz<BN>(er0, ec);       // chunk k of the thread sits RSTEP rows below chunk k - 1: a constant distance
-  auto epilogue = [&](unsigned outs, int tm, int tn) {
+  // bias of this lane's column runs: the block's column tile never changes, so it is fetched once, before the ring starts (a load
+  // inside the epilogue could only be used after every ring stage in flight had landed)
+  float4 bq[NT][4];
+#pragma unroll
+  for (int j = 0; j < NT; ++j)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int n = tn * BN + wn0 + j * 32 + 8 * g + 4 * hi;  // Nout is a multiple of 8: a run is inside or outside as a whole
+      bq[j][g] = (p.bias && n < p.Nout) ? *reinterpret_cast<const float4*>(p.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  // BatchNorm statistics (EPI = 1): a block owns its column tile for life, so every thread keeps RUNNING sums over all the rows it
+  // streams out -- count, and per channel the sum and the sum of squares of the deviations from the first value it saw (3 VALU per
+  // element; the deviations keep the sums small, so M2 = q - s^2 / n does not cancel) -- and the block folds them ONCE, after its
+  // last tile: one (n, mean, M2) record per block and channel (slice = the block's row group) instead of one per tile.
+  constexpr bool stats = EPI == 1;
+  float st_n = 0.f, st_ref[CH], st_s[CH], st_q[CH];
+#pragma unroll
+  for (int e = 0; e < CH; ++e) { st_ref[e] = 0.f; st_s[e] = 0.f; st_q[e] = 0.f; }
+  const bf16_t* __restrict__ ADDP = !ADD ? nullptr : (R ? R : (p.accumulate ? (const bf16_t*)D : nullptr));     // the addend read up front (residual or the running dx)
+  auto epilogue = [&](unsigned outs, int tm) {
     const int m0 = tm * BM, n0 = tn * BN;
+    const int n = n0 + ec * CH;
+    const int rows_left = M - (m0 + er0);                    // chunk k is inside the matrix iff k * RSTEP < rows_left
+    const size_t g0 = (size_t)(m0 + er0) * p.ldd + n;
+    // addends (residual / the gradient accumulated onto) and mask bytes of all this thread's chunks: in flight during the staging
+    uint4 qadd[ADD ? IT : 1]; unsigned mk[ADD ? IT : 1];
+    if constexpr (ADD) if (ADDP) {
+#pragma unroll
+      for (int k = 0; k < IT; ++k) {
+        qadd[k] = make_uint4(0, 0, 0, 0); mk[k] = 0xffu;
+        if (k * RSTEP < rows_left && n < p.Nout) {
+          const size_t g = g0 + (size_t)k * RSTEP * p.ldd;
+          qadd[k] = *reinterpret_cast<const uint4*>(ADDP + g);
+          if (p.acc_mask && !R) mk[k] = p.acc_mask[g / CH];
+        }
+      }
+    }
     asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");       // the last MFMAs' results before hipcc's reads of them (asm is opaque to its hazard pass)
-    RAW_BARRIER();                                           // every wave has finished reading this slot (last K step)
+    // (the staging region is this kernel's own: every wave left the previous tile's epilogue reads behind at one of the K-step
+    //  barriers since -- at least one per tile)
     if (!affine) {
 #pragma unroll
       for (int i = 0; i < MT; ++i)
@@ -276,14 +330,6 @@ __global__ __launch_bounds__(256) void pgemm_kernel(const GatherArgs p) {
             lds_write8(outs + so[j][g] + (unsigned)(i * 32 * BN * 2), u.q);
           }
     } else {
-      float4 bq[NT][4];                                      // bias of this lane's column runs, fetched up front
-#pragma unroll
-      for (int j = 0; j < NT; ++j)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const int n = n0 + wn0 + j * 32 + 8 * g + 4 * hi;  // Nout is a multiple of 8: a run is inside or outside as a whole
-          bq[j][g] = (p.bias && n < p.Nout) ? *reinterpret_cast<const float4*>(p.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
 #pragma unroll
       for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -299,13 +345,6 @@ __global__ __launch_bounds__(256) void pgemm_kernel(const GatherArgs p) {
     }
     LDS_WAIT_ALL();
     RAW_BARRIER();
-    constexpr bool stats = EPI == 1;
-    float sn = 0.f, smean[CH], sm2[CH];
-#pragma unroll
-    for (int e = 0; e < CH; ++e) { smean[e] = 0.f; sm2[e] = 0.f; }
-    const int n = n0 + ec * CH;
-    const int rows_left = M - (m0 + er0);                    // chunk k is inside the matrix iff k * RSTEP < rows_left
-    const size_t g0 = (size_t)(m0 + er0) * p.ldd + n;
     u32x4_t q[IT];
 #pragma unroll
     for (int k = 0; k < IT; ++k) q[k] = lds_read16u(outs + rd0 + (unsigned)(k * RSTEP * BN * 2));
@@ -319,68 +358,31 @@ __global__ __launch_bounds__(256) void pgemm_kernel(const GatherArgs p) {
       if (!stats && plain) { *reinterpret_cast<uint4*>(D + g) = qk; continue; }
       float v[CH]; Chunk<bf16_t>::unpack(qk, v);
       if (stats) {
-        sn += 1.f; const float inv = 1.f / sn;
+        if (st_n == 0.f) {
 #pragma unroll
-        for (int e = 0; e < CH; ++e) { const float d = v[e] - smean[e]; smean[e] += d * inv; sm2[e] += d * (v[e] - smean[e]); }
+          for (int e = 0; e < CH; ++e) st_ref[e] = v[e];
+        }
+        st_n += 1.f;
+#pragma unroll
+        for (int e = 0; e < CH; ++e) { const float d = v[e] - st_ref[e]; st_s[e] += d; st_q[e] += d * d; }
         if (plain) { *reinterpret_cast<uint4*>(D + g) = qk; continue; }
       }
-      if (R) { float w[CH]; Chunk<bf16_t>::load(R + g, w);
+      if constexpr (ADD) {
+        if (R) { float w[CH]; Chunk<bf16_t>::unpack(qadd[k], w);
 #pragma unroll
-        for (int e = 0; e < CH; ++e) v[e] += w[e]; }
-      if (p.accumulate) {
-        uint4 qa = *reinterpret_cast<const uint4*>(D + g);   // (mask applied on the packed words: see igemm.hip / DESIGN.md section 7)
-        if (p.acc_mask) qa = keep_masked<bf16_t>(qa, p.acc_mask[g / CH]);
-        float w[CH]; Chunk<bf16_t>::unpack(qa, w);
+          for (int e = 0; e < CH; ++e) v[e] += w[e]; }
+        if (p.accumulate) {
+          uint4 qa = R ? *reinterpret_cast<const uint4*>(D + g) : qadd[k];     // (both at once: not used by this model)
+          // the bit mask is applied on the packed words (see igemm.hip / DESIGN.md section 7)
+          if (p.acc_mask) qa = keep_masked<bf16_t>(qa, R ? (unsigned)p.acc_mask[g / CH] : mk[k]);
+          float w[CH]; Chunk<bf16_t>::unpack(qa, w);
 #pragma unroll
-        for (int e = 0; e < CH; ++e) v[e] += w[e]; }
+          for (int e = 0; e < CH; ++e) v[e] += w[e]; }
+      }
       if (p.relu) {
 #pragma unroll
         for (int e = 0; e < CH; ++e) v[e] = v[e] < 0.f ? 0.f : v[e]; }
       Chunk<bf16_t>::store(D + g, v);
-    }
-    if constexpr (stats) {
-      constexpr int NW = NTHR / 64;
-#pragma unroll
-      for (int o = CPR; o < 64; o <<= 1) {
-        const float nb = __shfl_down(sn, o, 64);
-        const float nt = sn + nb, f = nt > 0.f ? nb / nt : 0.f;
-#pragma unroll
-        for (int e = 0; e < CH; ++e) {
-          const float mb = __shfl_down(smean[e], o, 64), vb = __shfl_down(sm2[e], o, 64);
-          const float d = mb - smean[e];
-          smean[e] += d * f; sm2[e] += vb + d * d * sn * f;
-        }
-        sn = nt;
-      }
-      RAW_BARRIER();                                         // everyone is done reading the staged tile (reads were waited for above)
-      static_assert(NW * BN * 3 * 4 <= SM::kStage, "statistics scratch must fit in a ring slot");      // [NW][BN][3] floats
-      if (lane < CPR) {
-#pragma unroll
-        for (int e = 0; e < CH; ++e) {
-          const unsigned qa = outs + (unsigned)(((wave * BN + ec * CH + e) * 3) * 4);
-          lds_write4(qa, sn); lds_write4(qa + 4, smean[e]); lds_write4(qa + 8, sm2[e]);
-        }
-      }
-      LDS_WAIT_ALL();
-      RAW_BARRIER();
-      if (t < BN && n0 + t < p.Nout) {
-        float qn[NW], qm[NW], qv[NW];
-#pragma unroll
-        for (int w = 0; w < NW; ++w) {
-          const unsigned qa = outs + (unsigned)(((w * BN + t) * 3) * 4);
-          qn[w] = lds_read4(qa); qm[w] = lds_read4(qa + 4); qv[w] = lds_read4(qa + 8);
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(qn[0]), "+v"(qn[1]), "+v"(qn[2]), "+v"(qn[3]), "+v"(qm[0]), "+v"(qm[1]), "+v"(qm[2]),
-                     "+v"(qm[3]), "+v"(qv[0]), "+v"(qv[1]), "+v"(qv[2]), "+v"(qv[3]));
-        float cn = 0.f, mean = 0.f, m2 = 0.f;
-#pragma unroll
-        for (int w = 0; w < NW; ++w) {
-          const float nb = qn[w];
-          if (nb > 0.f) { const float nt = cn + nb, f = nb / nt, d = qm[w] - mean; mean += d * f; m2 += qv[w] + d * d * cn * f; cn = nt; }
-        }
-        float* out = p.stat_partial + ((size_t)tm * p.Nout + n0 + t) * 3;
-        out[0] = cn; out[1] = mean; out[2] = m2;
-      }
     }
   };
 
@@ -389,69 +391,149 @@ __global__ __launch_bounds__(256) void pgemm_kernel(const GatherArgs p) {
 #pragma unroll
   for (int d = 0; d < DIST; ++d)
     if (is_gs < total) issue();
-  int kt = 0, tile_i = 0;
+  int kt = 0, tile_i = 0, cur_slot = 0;
+  unsigned epi_hist = 0;                                      // bit d: the K step d + 1 steps ago ended with a full tile's epilogue
+  const bool full_cols = (tn + 1) * BN <= p.Nout;
   for (int gs = 0; gs < total; ++gs) {
     // this wave's pieces of stage gs have landed once at most the pieces of the DIST-1 younger stages are outstanding
     // (LDS-DMA, loads and stores retire in issue order; anything the epilogue issued meanwhile is younger still: waiting for
     // more than needed is safe, never for less)
 #if defined(__HIP_DEVICE_COMPILE__)
     if (gs + DIST - 1 < total && DIST > 1) {
-      if constexpr ((DIST - 1) * (PA + PB) == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-      else if constexpr ((DIST - 1) * (PA + PB) == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-      else if constexpr ((DIST - 1) * (PA + PB) == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-      else if constexpr ((DIST - 1) * (PA + PB) == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-      else if constexpr ((DIST - 1) * (PA + PB) == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      // vmcnt counts this wave's vector-memory instructions of every kind, in order: behind stage gs's pieces came the pieces of
+      // the DIST - 1 younger stages AND the output stores of every epilogue run since (IT store instructions per FULL tile --
+      // a lower bound: partial tiles, residual / accumulate loads and statistics stores are not counted, which only waits longer).
+      // Counting the ring loads alone let a tile's stores eat the allowance: with one K step per tile the ring ran one deep.
+      constexpr int W = (DIST - 1) * PA;
+      const int c = __builtin_amdgcn_readfirstlane(__builtin_popcount(epi_hist & ((1u << DIST) - 1u)));       // full-tile epilogues within the last DIST steps
+      switch (c) {
+        case 0: wait_vm<W>(); break;
+        case 1: wait_vm<W + IT>(); break;
+        case 2: wait_vm<W + 2 * IT>(); break;
+        case 3: wait_vm<W + 3 * IT>(); break;
+        case 4: wait_vm<W + 4 * IT>(); break;
+        case 5: wait_vm<W + 5 * IT>(); break;
+        case 6: wait_vm<W + 6 * IT>(); break;
+        default: wait_vm<W + 7 * IT>(); break;
+      }
     } else {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
 #endif
     RAW_BARRIER();                                           // everyone's pieces have; slot (gs - 1) % NS is no longer read
     if (is_gs < total) issue();                              // stage gs + DIST -> the slot stage gs - 1 has just left
-    const unsigned as = smem_base + (unsigned)((gs % NS) * SM::kStage);
+    const unsigned as = ring_base + (unsigned)(cur_slot * SM::kStage);
+    if (++cur_slot == NS) cur_slot = 0;
     __builtin_amdgcn_s_setprio(1);
-    compute(as, __builtin_amdgcn_readfirstlane(kt == 0 ? 1 : 0));
+    compute(as, smem_base + (unsigned)(kt * BN * 128), __builtin_amdgcn_readfirstlane(kt == 0 ? 1 : 0));
     __builtin_amdgcn_s_setprio(0);
+    epi_hist <<= 1;
     if (++kt == nk) {
-      const int lin = tile_i * G + pos, tm = lin / ntn, tn = lin - tm * ntn;
-      epilogue(as, tm, tn);
+      const int tm = gm + tile_i * Gm;
+      epilogue(out_base, tm);
+      if (full_cols && (tm + 1) * BM <= M) epi_hist |= 1u;
       kt = 0; ++tile_i;
+    }
+  }
+  if constexpr (stats) {
+    // ---- the block's statistics record: per thread (n, ref, s, q) -> (n, mean, M2); row lanes of a wave by shuffle-down (lower lane =
+    // left operand), the waves in wave order through LDS: a fixed order, bitwise reproducible
+    constexpr int NW = NTHR / 64;
+    const int n0 = tn * BN;
+    float sn = st_n, smean[CH], sm2[CH];
+    const float inv = sn > 0.f ? 1.f / sn : 0.f;
+#pragma unroll
+    for (int e = 0; e < CH; ++e) { smean[e] = st_ref[e] + st_s[e] * inv; sm2[e] = st_q[e] - st_s[e] * st_s[e] * inv; sm2[e] = sm2[e] < 0.f ? 0.f : sm2[e]; }
+#pragma unroll
+    for (int o = CPR; o < 64; o <<= 1) {
+      const float nb = __shfl_down(sn, o, 64);
+      const float nt = sn + nb, f = nt > 0.f ? nb / nt : 0.f;
+#pragma unroll
+      for (int e = 0; e < CH; ++e) {
+        const float mb = __shfl_down(smean[e], o, 64), vb = __shfl_down(sm2[e], o, 64);
+        const float d = mb - smean[e];
+        smean[e] += d * f; sm2[e] += vb + d * d * sn * f;
+      }
+      sn = nt;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    RAW_BARRIER();                                           // every wave has left the last epilogue: the staging region is free
+    static_assert(NW * BN * 3 * 4 <= SM::kOut, "statistics scratch must fit in the staging region");      // [NW][BN][3] floats
+    if (lane < CPR) {
+#pragma unroll
+      for (int e = 0; e < CH; ++e) {
+        const unsigned qa = out_base + (unsigned)(((wave * BN + ec * CH + e) * 3) * 4);
+        lds_write4(qa, sn); lds_write4(qa + 4, smean[e]); lds_write4(qa + 8, sm2[e]);
+      }
+    }
+    LDS_WAIT_ALL();
+    RAW_BARRIER();
+    if (t < BN && n0 + t < p.Nout) {
+      float qn[NW], qm[NW], qv[NW];
+#pragma unroll
+      for (int w = 0; w < NW; ++w) {
+        const unsigned qa = out_base + (unsigned)(((w * BN + t) * 3) * 4);
+        qn[w] = lds_read4(qa); qm[w] = lds_read4(qa + 4); qv[w] = lds_read4(qa + 8);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(qn[0]), "+v"(qn[1]), "+v"(qn[2]), "+v"(qn[3]), "+v"(qm[0]), "+v"(qm[1]), "+v"(qm[2]),
+                   "+v"(qm[3]), "+v"(qv[0]), "+v"(qv[1]), "+v"(qv[2]), "+v"(qv[3]));
+      float cn = 0.f, mean = 0.f, m2 = 0.f;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) {
+        const float nb = qn[w];
+        if (nb > 0.f) { const float nt = cn + nb, f = nb / nt, d = qm[w] - mean; mean += d * f; m2 += qv[w] + d * d * cn * f; cn = nt; }
+      }
+      float* out = p.stat_partial + ((size_t)gm * p.Nout + n0 + t) * 3;
+      out[0] = cn; out[1] = mean; out[2] = m2;
     }
   }
 }
 
 // ------------------------------------------------------------------------------------ host
-template <int BM, int BN, int NS, int EPI>
-static void launch_pgemm_epi(GatherArgs& a, int grid, hipStream_t st) {
-  constexpr int smem = PgSmem<BM, BN, NS>::kBytes;
-  auto kern = pgemm_kernel<BM, BN, NS, EPI>;
-  static bool attr_set = false;
-  if (!attr_set) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem); attr_set = true; }
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), smem, st, a);
+template <int BM, int BN, int NS, int EPI, bool ADD>
+static void launch_pgemm_epi(GatherArgs& a, int ncu, int ntm, int smem, hipStream_t st) {
+  auto kern = pgemm_kernel<BM, BN, NS, EPI, ADD>;
+  static int attr = 0;       // dynamic-LDS cap raised so far for this instantiation
+  if (smem > attr) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem); attr = smem; }
+  // blocks that really share a CU at this LDS size (the persistent grid must not exceed what is resident, or late blocks queue)
+  static int occ_smem[4] = {0, 0, 0, 0}, occ_n[4] = {0, 0, 0, 0};
+  int per_cu = 0;
+  for (int i = 0; i < 4; ++i) if (occ_smem[i] == smem) per_cu = occ_n[i];
+  if (!per_cu) {
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, 256, (size_t)smem) != hipSuccess || nb < 1) nb = 1;
+    per_cu = nb;
+    for (int i = 0; i < 4; ++i) if (!occ_smem[i]) { occ_smem[i] = smem; occ_n[i] = nb; break; }
+  }
+  static const int cap = getenv("MI355_PG_PER_CU") ? atoi(getenv("MI355_PG_PER_CU")) : 2;
+  if (per_cu > cap) per_cu = cap;
+  // every block owns one column tile: the grid is a whole number of (row group, column tile) pairs, at most one per row tile
+  int groups = ncu * per_cu / a.ntn; if (groups < 1) groups = 1;
+  if (groups > ntm) groups = ntm;
+  if (EPI == 1) a.stat_slices = groups;      // one statistics record per block and channel (slice = row group; groups <= ntm fits, checked by the caller)
+  hipLaunchKernelGGL(kern, dim3(groups * a.ntn), dim3(256), smem, st, a);
 }
 template <int BM, int BN, int NS>
-static void launch_pgemm(GatherArgs& a, int ncu, hipStream_t st) {
+static bool launch_pgemm(GatherArgs& a, int ncu, hipStream_t st) {
+  const int nk = a.Ci >> 6;
+  const int smem = PgSmem<BM, BN, NS>::bytes(nk);
+  if (smem > 160 * 1024) return false;
   const int ntm = cdiv(a.ph[0].M, BM);
   a.ntn = cdiv(a.Nout, BN);
   a.ph[0].ntm = ntm;
   a.ntiles = ntm * a.ntn;
   a.stat_slices = 0;
-  if (a.stat_partial) {
-    if (!a.residual && !a.accumulate && (size_t)ntm * a.Nout * 3 * sizeof(float) <= a.stat_bytes) a.stat_slices = ntm;
-    else a.stat_partial = nullptr;
-  }
-  constexpr int per_cu_lds = (160 * 1024) / PgSmem<BM, BN, NS>::kBytes;  // blocks that fit a CU's LDS
-  constexpr int per_cu = per_cu_lds < 4 ? per_cu_lds : 4;
-  static const int cap = getenv("MI355_PG_PER_CU") ? atoi(getenv("MI355_PG_PER_CU")) : 8;
-  int grid = ncu * (per_cu < cap ? per_cu : cap);
-  if (grid > a.ntiles) grid = a.ntiles;
-  if (a.stat_partial) launch_pgemm_epi<BM, BN, NS, 1>(a, grid, st);
-  else launch_pgemm_epi<BM, BN, NS, 0>(a, grid, st);
+  if (a.stat_partial && (a.residual || a.accumulate || (size_t)ntm * a.Nout * 3 * sizeof(float) > a.stat_bytes)) a.stat_partial = nullptr;
+  if (a.stat_partial) launch_pgemm_epi<BM, BN, NS, 1, false>(a, ncu, ntm, smem, st);
+  else if (a.residual || a.accumulate) launch_pgemm_epi<BM, BN, NS, 0, true>(a, ncu, ntm, smem, st);
+  else launch_pgemm_epi<BM, BN, NS, 0, false>(a, ncu, ntm, smem, st);
+  return true;
 }
 
 // Does the launch described by `a` (filled as for dispatch_gather) fit this kernel?  1x1, unit stride both ways (GEMM rows =
-// NHWC pixels in order), bf16, whole 64-channel K steps, no BatchNorm-backward epilogue, no heat-map output.
-static int g_pgemm_mode = -1;        // run-time switch (mi355_set_pgemm); -1: the environment decides (MI355_PGEMM, default 0)
+// NHWC pixels in order), bf16, whole 64-channel K steps, a weight slice of one column tile that fits LDS beside the ring, no
+// BatchNorm-backward epilogue, no heat-map output, no concatenated second operand.
+static int g_pgemm_mode = -1;        // run-time switch (mi355_set_pgemm); -1: the environment decides (MI355_PGEMM, default 1)
 // 0: never; 1: where it measured faster than the gather kernel (below); 2: wherever the launch fits the kernel (tests, A/B runs).
 // Returns the previous setting.
 extern "C" int mi355_set_pgemm(int mode) {
@@ -459,11 +541,16 @@ extern "C" int mi355_set_pgemm(int mode) {
   g_pgemm_mode = mode < 0 ? -1 : (mode > 2 ? 2 : mode);
   return prev;
 }
+static int pg_bn(const GatherArgs& a) {       // column tile: the widest whose weight slice [BN][K] stays within 64 KB
+  if (a.Nout > 64 && (long)a.Ci * 128 * 2 <= 64 * 1024) return 128;
+  if ((long)a.Ci * 64 * 2 <= 64 * 1024) return 64;
+  return 0;
+}
 bool pgemm_eligible(const GatherArgs& a, int elem_size) {
-  static const int env_mode = getenv("MI355_PGEMM") ? atoi(getenv("MI355_PGEMM")) : 0;
+  static const int env_mode = getenv("MI355_PGEMM") ? atoi(getenv("MI355_PGEMM")) : 1;
   const int mode = g_pgemm_mode >= 0 ? g_pgemm_mode : env_mode;
   if (!mode || elem_size != 2) return false;
-  if (a.nphase != 1 || a.ph[0].ntaps != 1) return false;
+  if (a.nphase != 1 || a.ph[0].ntaps != 1 || a.A2) return false;
   const Tap& tp = a.taps[a.ph[0].tap0];
   if (tp.dy != 0 || tp.dx != 0 || tp.widx != 0) return false;
   if (a.in_sx != 1 || a.in_sy != 1 || a.out_sx != 1 || a.out_sy != 1) return false;
@@ -472,14 +559,17 @@ bool pgemm_eligible(const GatherArgs& a, int elem_size) {
   if (a.bnb_partial || a.hw) return false;
   const long Mrows = a.ph[0].M;
   if (Mrows * a.Ci * 2 >= (1L << 31) || Mrows * a.Nout * 2 >= (1L << 31)) return false;
-  if (Mrows < 256) return false;
+  if (Mrows < 256 || !pg_bn(a)) return false;
   if (mode >= 2) return true;
-  // Where it wins (profiles/r03_pgemm_phases.txt, graph-timed per layer): not with the BatchNorm-statistics epilogue (one or two
-  // blocks per CU cannot hide its VALU work behind other blocks' MFMAs as the gather kernel's three or four do); otherwise on
-  // K-heavy layers, narrow outputs and small row counts; K = 64 .. 256 with wide outputs and many rows is HBM-bound on both
-  // kernels and the gather kernel's higher occupancy keeps more bytes in flight there.
-  if (a.stat_partial) return false;
-  return a.Ci >= 512 || a.Nout <= 64 || Mrows <= 16384;
+  // the epilogues that read global memory (residual, accumulate) stay on the gather kernel: a wave consumes vector-memory results
+  // in issue order, so using such a load waits for every ring stage in flight -- one memory latency per tile
+  if (a.residual || a.accumulate) return false;
+  // Where it wins against the gather kernel (profiles/r04_pgemm_layers.txt: per layer, operands from HBM): the large maps
+  // (>= 32 K rows), with a short K (<= 128: wide outputs stream at 5 TB/s) or a narrow output (K = 256 -> 64 / 128 columns).
+  // K = 256 -> 256 columns needs two column tiles, i.e. the activations twice (no gain), K = 512 leaves room for 64-wide
+  // column tiles only (slower).
+  static const long min_rows = getenv("MI355_PG_MIN_ROWS") ? atol(getenv("MI355_PG_MIN_ROWS")) : 32768;
+  return Mrows >= min_rows && (a.Ci <= 128 || (a.Ci <= 256 && a.Nout <= 128));
 }
 
 int dispatch_pgemm(GatherArgs& a, hipStream_t st) {
@@ -490,27 +580,32 @@ int dispatch_pgemm(GatherArgs& a, hipStream_t st) {
       MI_FAIL(MI355_ELAUNCH, "pgemm: cannot read the CU count");
     ncu = v;
   }
-  const long M = a.ph[0].M;
-  static const int force = getenv("MI355_PG_TILE") ? atoi(getenv("MI355_PG_TILE")) : -1;     // experiment switch
-  const long t128 = cdiv(M, 128L) * cdiv(a.Nout, 128);
-  int sel;
-  if (force >= 0) sel = force;
-  else if (a.Nout <= 64) sel = cdiv(M, 128L) >= 2 * ncu ? 2 : 3;
-  else if (t128 >= 2 * ncu) sel = 0;
-  else if (cdiv(M, 64L) * cdiv(a.Nout, 128) >= 2 * ncu) sel = 1;
-  else sel = 3;
-  switch (sel) {
-    case 0: launch_pgemm<128, 128, 3>(a, ncu, st); break;
-    case 1: launch_pgemm<64, 128, 3>(a, ncu, st); break;
-    case 2: launch_pgemm<128, 64, 3>(a, ncu, st); break;
-    case 3: launch_pgemm<64, 64, 3>(a, ncu, st); break;
-    case 4: launch_pgemm<128, 128, 2>(a, ncu, st); break;
-    case 5: launch_pgemm<64, 128, 2>(a, ncu, st); break;
-    case 6: launch_pgemm<64, 64, 2>(a, ncu, st); break;
-    case 7: launch_pgemm<64, 128, 4>(a, ncu, st); break;
-    case 8: launch_pgemm<64, 64, 4>(a, ncu, st); break;
-    default: MI_FAIL(MI355_EINVAL, "pgemm: MI355_PG_TILE=%d", sel);
+  static const int ring_env = getenv("MI355_PG_RING") ? atoi(getenv("MI355_PG_RING")) : 0;        // experiment switches
+  static const int bm = getenv("MI355_PG_BM") ? atoi(getenv("MI355_PG_BM")) : 64;
+  const int bn = pg_bn(a);
+  const int nk = a.Ci >> 6;
+  // ring depth: the deepest ring with which TWO blocks still share a CU (each hides the other's epilogue), else the deepest that fits
+  int ring = ring_env;
+  if (!ring) {
+    const int fixed = nk * bn * 128 + 64 * bn * 2;
+    for (int ns : {8, 6, 5, 4}) if (!ring && fixed + ns * 64 * 128 <= 80 * 1024) ring = ns;
+    for (int ns : {8, 6, 5, 4}) if (!ring && fixed + ns * 64 * 128 <= 160 * 1024) ring = ns;
   }
+  bool ok = false;
+  if (bn == 128) {
+    if (bm == 128) ok = launch_pgemm<128, 128, 4>(a, ncu, st);
+    else if (ring == 8) ok = launch_pgemm<64, 128, 8>(a, ncu, st);
+    else if (ring == 6) ok = launch_pgemm<64, 128, 6>(a, ncu, st);
+    else if (ring == 5) ok = launch_pgemm<64, 128, 5>(a, ncu, st);
+    else ok = launch_pgemm<64, 128, 4>(a, ncu, st);
+  } else {
+    if (bm == 128) ok = launch_pgemm<128, 64, 4>(a, ncu, st);
+    else if (ring == 8) ok = launch_pgemm<64, 64, 8>(a, ncu, st);
+    else if (ring == 6) ok = launch_pgemm<64, 64, 6>(a, ncu, st);
+    else if (ring == 5) ok = launch_pgemm<64, 64, 5>(a, ncu, st);
+    else ok = launch_pgemm<64, 64, 4>(a, ncu, st);
+  }
+  if (!ok) MI_FAIL(MI355_EINVAL, "pgemm: the weight slice of K = %d channels does not fit LDS (bn %d)", a.Ci, bn);
   MI_CHECK_LAUNCH("pgemm");
   return MI355_OK;
 }

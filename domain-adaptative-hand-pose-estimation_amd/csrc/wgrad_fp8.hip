@@ -392,6 +392,7 @@ extern "C" int mi355_conv_wgrad_fp8(const mi355_conv_desc* d, const void* x8, in
   if (!direct && (ws == nullptr || ws_bytes < need)) MI_FAIL(MI355_EWORKSPACE, "wgrad_fp8 workspace %zu < %zu", ws_bytes, need);
   const long M = (long)d->N * d->Ho * d->Wo, slab = (long)d->Co * w.ldw;
   const unsigned xb = (unsigned)((long)d->N * d->Hi * d->Wi * d->Ci), yb = (unsigned)(M * d->Co);
+  if (prof_on()) prof_set_tag("wgrad8 k%ds%d %d>%d @%dx%d n%d", d->kh, d->stride, d->Ci, d->Co, d->Hi, d->Wi, d->N);
   ProfScope ps(st, 2.0 * M * (double)d->Co * w.ldw, (double)xb + (double)yb + 4.0 * d->Co * w.ldw);
   dim3 grid(w.nto * d->kh * w.nti * w.S);
   if (w.s2) {

@@ -114,6 +114,9 @@ SIGNATURES = {
     'mi355_prof_read_split': (_I, [ctypes.c_double, ctypes.POINTER(ctypes.c_double)]),
     'mi355_prof_event_overhead_us': (_I, [_I, _P, ctypes.POINTER(ctypes.c_double)]),
     'mi355_prof_reset': (_I, []),
+    'mi355_prof_launch_count': (_I, [ctypes.POINTER(ctypes.c_long)]),
+    'mi355_prof_read_launch': (_I, [_L, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double),
+                                    ctypes.POINTER(ctypes.c_double), ctypes.c_char_p, _I]),
     'mi355_prof_read': (_I, [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_long),
                              ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]),
 }

@@ -378,6 +378,20 @@ def _take_partial(mod, y):
     return y
 
 
+def _zero_grad_once(g):
+    """g (the gradient buffer of a bias) <- 0, skipped when this very tensor object still holds the zeros this function wrote last
+    time: nothing but this module's bias-gradient code writes non-zeros into it (the optimizer and the gradient exchange read it; a
+    mean of zeros is zero; zero_grad only marks it fresh), and a re-created gradient tensor (flattening by FusedSGD, set_to_none)
+    is a new object without the mark.  An iteration's ~20 zero-fill launches become none (none is captured into the HIP graphs)."""
+    mark = getattr(g, '_mi_zeroed', None)
+    # a stand-alone gradient tensor also proves by its version counter that no torch op touched it since; views of FusedSGD's flat
+    # buffer share the buffer's counter (every neighbour's zero_ moves it), there the mark alone decides
+    if mark is not None and mark is not False and (g._base is not None or mark == g._version):
+        return
+    g.zero_()
+    g._mi_zeroed = g._version
+
+
 def _bias_grad(ctx, bias, dy):
     """Bias gradient of a conv = column sum of dy.  When the conv's output went straight into a training-mode BatchNorm (which
     consumed the statistics fused into this conv's epilogue and said so: ctx.bias_grad_zero), dy is that BatchNorm's input
@@ -391,8 +405,9 @@ def _bias_grad(ctx, bias, dy):
     from_bn = ent is not None and ent.shape == dy.shape and ent.dtype == dy.dtype
     if getattr(ctx, 'bias_grad_zero', False) and from_bn and _ZERO_BN_BIAS_GRAD:
         if not acc:
-            g.zero_()
+            _zero_grad_once(g)
         return
+    g._mi_zeroed = False
     ops.colsum(dy, g, acc)
 
 
@@ -872,8 +887,9 @@ class _ConvCatFn(torch.autograd.Function):
                 g, acc = grad_slot(b)
                 if zero:
                     if not acc:
-                        g.zero_()
+                        _zero_grad_once(g)
                 else:
+                    g._mi_zeroed = False
                     ops.colsum(dout, g, acc)
         if ctx.needs_input_grad[2]:
             _conv_wgrad(ctx, x, dout, wf)

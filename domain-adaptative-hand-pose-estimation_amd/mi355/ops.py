@@ -654,6 +654,19 @@ def prof_reset():
     call('mi355_prof_reset')
 
 
+def prof_launches():
+    """Every launch logged since the last reset, in launch order: dicts with family, us (event-timed), flops, bytes, label."""
+    n = ctypes.c_long()
+    call('mi355_prof_launch_count', ctypes.byref(n))
+    out = []
+    fam, us, fl, by = ctypes.c_int(), ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
+    buf = ctypes.create_string_buffer(192)
+    for i in range(n.value):
+        call('mi355_prof_read_launch', i, ctypes.byref(fam), ctypes.byref(us), ctypes.byref(fl), ctypes.byref(by), buf, 192)
+        out.append({'family': fam.value, 'us': us.value, 'flops': fl.value, 'bytes': by.value, 'label': buf.value.decode()})
+    return out
+
+
 def prof_read():
     ms, n, fl, by = ctypes.c_double(), ctypes.c_long(), ctypes.c_double(), ctypes.c_double()
     call('mi355_prof_read', ctypes.byref(ms), ctypes.byref(n), ctypes.byref(fl), ctypes.byref(by))

@@ -14,6 +14,7 @@ class _KLFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, pred, target, weight, eps, coeff):
+        ctx.set_materialize_grads(False)      # `rows` is rarely differentiated: no zero tensor per call for its absent gradient
         rows, g = ops.kl_heatmap(pred, target, weight, eps, ctx.needs_input_grad[0], coeff)
         ctx.save_for_backward(g)
         return ops.reduce_sum(rows.view(-1), float(coeff) / rows.numel()), rows
@@ -21,7 +22,7 @@ class _KLFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gout, grows):
         g, = ctx.saved_tensors
-        if g is None:
+        if g is None or gout is None:
             return None, None, None, None, None
         if _rt.is_unit_grad(gout):
             return g, None, None, None, None

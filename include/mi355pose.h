@@ -372,9 +372,16 @@ int mi355_sgd_nesterov(float* p, const float* g, float* buf, long n, const float
 int mi355_cast_f32(const float* in, void* out, long n, int dtype, void* stream);
 
 /* ---------------------------------------------------------------- in-library kernel timing (bench.py roofline)
- * When enabled, every launch of the MFMA conv family is bracketed by hipEvents on its stream.
- * mi355_prof_read synchronises the recorded events and returns totals since the last reset. */
+ * on = 1: every launch of the MFMA conv family is bracketed by hipEvents on its stream; on = 2: the BatchNorm kernels and
+ * the weight-gradient slab reductions as well (family 1 / 2; they never enter the totals below).  mi355_prof_read
+ * synchronises the recorded events and returns the conv family's totals since the last reset. */
 int mi355_prof_enable(int on);
+/* The launches logged since the last reset, one by one in launch order: family (0 conv MFMA, 1 BatchNorm, 2 other), event-timed
+ * duration in microseconds (contains the dispatch latency mi355_prof_event_overhead_us measures), algorithmic FLOPs and bytes,
+ * and a label naming the layer ("fwd k3s1 256>256 @64x64 n64 +stats", "bn_bwd_res rows262144 C256 ...").  Each entry is ONE
+ * kernel launch, so the list joins in order with a rocprofv3 kernel trace of the same iteration (profiles/insitu_table.py). */
+int mi355_prof_launch_count(long* n);
+int mi355_prof_read_launch(long i, int* family, double* us, double* flops, double* bytes, char* label, int label_cap);
 /* idle spin of `us` microseconds on the stream (measurement aid: queue launches behind it so the GPU never waits for the host) */
 int mi355_spin_us(long us, void* stream);
 /* the timed launches split at an arithmetic intensity (FLOP / byte): out[0..3] = {ms, flops, bytes, launches} below it, out[4..7] above */

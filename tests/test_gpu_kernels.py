@@ -194,20 +194,23 @@ def test_conv_kernels_give_the_same_bits_run_after_run(gpu, case):
 
 
 PGEMM_CASES = [
-    # N, Ci, H, W, Co : 1x1 / unit-stride layers; one case per tile choice of dispatch_pgemm, ragged rows / column tails, 1 .. 32 K steps
+    # N, Ci, H, W, Co : 1x1 / unit-stride layers; one case per column-tile / ring choice of dispatch_pgemm, ragged rows, column tails
     (3, 128, 8, 8, 256),        # 192 rows: below the kernel's floor -> stays on the gather kernel whatever the mode (control)
-    (3, 64, 9, 13, 256),        # 351 rows (ragged: partial row tiles), one K step, 64 x 64 tiles
-    (4, 128, 16, 16, 64),       # two K steps, narrow output
-    (64, 1024, 16, 16, 256),    # 16 K steps, 64 x 128 tiles, two blocks per CU, one tile per block
-    (64, 256, 16, 16, 1024),    # 128 x 128 tiles, four tiles per persistent block
-    (16, 64, 64, 64, 64),       # 65536 rows, 128 x 64 tiles, many tiles per block
-    (64, 2048, 8, 8, 512),      # 32 K steps
+    (2, 1024, 16, 16, 256),     # K = 1024: no weight slice fits LDS -> stays on the gather kernel (control)
+    (3, 64, 9, 13, 256),        # 351 rows (ragged: partial row tiles), one K step, two 128-wide column tiles
+    (4, 128, 16, 16, 64),       # two K steps, 64-wide column tile
+    (16, 64, 64, 64, 64),       # 65536 rows: many row tiles per persistent block, ring of 8
+    (8, 256, 32, 32, 256),      # four K steps, 64-KB weight slice, one block per CU
+    (8, 512, 16, 16, 128),      # K = 512: 64-wide column tiles, eight K steps
+    (5, 128, 24, 24, 256),      # 2880 rows = 45 row tiles over two column tiles
+    (64, 256, 16, 16, 1024),    # eight column tiles
+    (64, 64, 64, 64, 256),      # make-or-break shape of the iteration: 64 -> 256 @64x64, B = 64
 ]
 
 
 @pytest.mark.parametrize('case', PGEMM_CASES)
 def test_pgemm_matches_the_gather_kernel_bit_for_bit(gpu, case):
-    """The persistent pipelined GEMM (csrc/pgemm.hip) and the gather kernel run the same MFMA sequence per output element: every
+    """The weights-stationary streaming GEMM (csrc/pgemm.hip) and the gather kernel run the same MFMA sequence per output element: every
     epilogue form must give IDENTICAL bits on both (forward plain / bias / bias + residual + ReLU, input gradient plain / scaled
     accumulate / bit-masked accumulate); the fused BatchNorm statistics must agree per channel once folded; and the forward
     must agree with a torch matmul within the bf16 tolerance."""
