@@ -3,8 +3,8 @@
 hipcc cross-compiles without a GPU.  Objects are cached under csrc/_build/ by source mtime.
 
 After linking, the device code of the library is disassembled and checked (`isa_gate`): the build FAILS when it contains a
-packed-fp32 arithmetic instruction (v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32) whose LOW result is taken from the high
-register of an operand pair (an `op_sel:[...]` with a 1 in it).  That instruction form lost its swapped operand in lanes
+packed-fp32 arithmetic instruction (any VOP3P `v_pk_*_f32` opcode) that takes an operand half from the OTHER register of its
+pair (an `op_sel:[...]` with a 1 in it, or an `op_sel_hi:[...]` with a 0 in it).  That instruction form lost its swapped operand in lanes
 48-63 of the conv accumulate epilogue now and then on MI355X (round 2; established in round 3 by replacing only that
 instruction in the kernel's assembly -- the src1-swapped form fails, the src0-swapped one did not in that kernel; the gate
 refuses both: DESIGN.md section 7 "dropped addend", profiles/dropped_addend_repro.py).  The
@@ -33,8 +33,9 @@ FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-u
          '-ffp-contract=off',       # no implicit FMA contraction: keep fp32 parity with the ATen op order
          '-fno-slp-vectorize']      # no packed fp32 VALU formed from scalar code (see the module docstring / isa_gate)
 
-_PK = re.compile(r'\bv_pk_(add|mul|fma)_f32\b')
-_OPSEL = re.compile(r'\bop_sel:\[([01,]+)\]')
+_PK = re.compile(r'\bv_pk_[a-z0-9_]+_f32\b')             # every VOP3P fp32-pair arithmetic opcode (add, mul, fma and whatever else the ISA grows)
+_OPSEL = re.compile(r'\bop_sel:\[([01,]+)\]')           # default [0,0(,0)]: low results from the low registers
+_OPSEL_HI = re.compile(r'\bop_sel_hi:\[([01,]+)\]')     # default [1,1(,1)]: high results from the high registers
 
 
 def _negated(flag):
@@ -81,16 +82,22 @@ def device_disassembly(so_path):
         shutil.rmtree(tmp, ignore_errors=True)
 
 
+def swaps_halves(ins):
+    """True for a packed-fp32 arithmetic instruction that takes an operand half from the other register of its pair."""
+    if not _PK.search(ins):
+        return False
+    m, h = _OPSEL.search(ins), _OPSEL_HI.search(ins)
+    return bool((m and '1' in m.group(1)) or (h and '0' in h.group(1)))
+
+
 def isa_gate(so_path):
     """Fail on packed-fp32 arithmetic whose low result reads the high register of an operand pair (module docstring).
     Returns the number of device instructions inspected."""
     n, hits = 0, []
     for sym, ins in device_disassembly(so_path):
         n += 1
-        if _PK.search(ins):
-            m = _OPSEL.search(ins)
-            if m and '1' in m.group(1):
-                hits.append('%s: %s' % (sym, ins))
+        if swaps_halves(ins):
+            hits.append('%s: %s' % (sym, ins))
     if n < 1000:
         raise RuntimeError('isa gate: only %d device instructions found in %s -- the disassembly step is broken' % (n, so_path))
     if hits:
@@ -141,6 +148,33 @@ def build(force=False, verbose=True, extra_flags=(), variant=None, gate=True):
                 os.remove(out)          # a library that fails the gate must not be loadable
                 raise
     return out
+
+
+def build_host_sanitized(out_dir, driver_src, verbose=False):
+    """CPU-box sanitizer job: the HOST pass of every .hip source compiled with AddressSanitizer +
+    UndefinedBehaviorSanitizer (`-fno-gpu-sanitize`: the device code is built as usual, no GPU sanitizer is involved) and linked with
+    `driver_src` into one executable, which is returned.  The driver exercises the host halves of the entry points --
+    descriptor checks, tap / phase tables, split plans, grouped argument blocks, workspace sizing -- on a machine without a GPU:
+    launches fail in the HIP runtime after the host code under test has run."""
+    os.makedirs(out_dir, exist_ok=True)
+    san = ['-fsanitize=address,undefined', '-fno-sanitize-recover=undefined', '-fno-omit-frame-pointer', '-g', '-O1']
+    base = ['--offload-arch=gfx950', '-fno-gpu-sanitize', '-std=c++17', '-fPIC', '-Wno-unused-function', '-ffp-contract=off', '-fno-slp-vectorize'] + san
+
+    def cc(src):
+        obj = os.path.join(out_dir, os.path.basename(src).rsplit('.', 1)[0] + '.o')
+        cmd = [HIPCC] + base + (['-x', 'hip'] if src.endswith('.cpp') else []) + ['-c', src, '-o', obj]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError('sanitizer build failed for %s:\n%s' % (src, r.stderr[-4000:]))
+        return obj
+
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        objs = list(ex.map(cc, [os.path.join(CSRC, s) for s in SOURCES] + [driver_src]))
+    exe = os.path.join(out_dir, 'host_sanitize_driver')
+    r = subprocess.run([HIPCC, '--offload-arch=gfx950', '-fno-gpu-sanitize'] + san + ['-o', exe] + objs, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError('sanitizer link failed:\n' + r.stderr[-4000:])
+    return exe
 
 
 if __name__ == '__main__':

@@ -274,76 +274,7 @@ def workspace(nbytes, device, tag='main'):
     return buf
 
 
-# ---------------------------------------------------------------- side stream for weight gradients
-# Weight gradients are off the critical path of a backward pass (only the optimizer reads them), so they are
-# enqueued on a second HIP stream and overlap the dgrad / BatchNorm-backward chain; `join_side()` is the single
-# rendezvous before the optimizer kernels.  Inputs of in-flight side work are kept referenced until the join, so
-# the caching allocator cannot hand their memory to the main stream early (works inside graph capture too: the
-# side stream forks from and rejoins the capturing stream through events).
 import os as _os
-
-_side = {}
-_pending = []
-# measured on MI355X (ResNet-50, B=64): 51.3 ms/iteration without, 52.1 ms with -> off by default
-SIDE_WGRAD = _os.environ.get('MI355_WGRAD_STREAM', '0') != '0'
-# MI355_WGRAD_STREAM=N with N > 1: only weight gradients of layers with at most N output rows go to the side stream
-SIDE_WGRAD_MAX_ROWS = int(_os.environ.get('MI355_WGRAD_STREAM', '0')) if int(_os.environ.get('MI355_WGRAD_STREAM', '0')) > 1 else None
-
-
-def side_wgrad_for(desc):
-    if not SIDE_WGRAD:
-        return False
-    return SIDE_WGRAD_MAX_ROWS is None or desc.N * desc.Ho * desc.Wo <= SIDE_WGRAD_MAX_ROWS
-
-
-def side_stream(device):
-    key = device.index if device.index is not None else torch.cuda.current_device()
-    st = _side.get(key)
-    if st is None:
-        st = _side[key] = torch.cuda.Stream(device=device)
-    return st
-
-
-class on_side:
-    """with on_side(device, keep=(x, dy)): ...  -> body runs on the side stream, ordered after the work already
-    enqueued on the current stream."""
-
-    def __init__(self, device, keep=()):
-        self.dev, self.keep = device, keep
-
-    def __enter__(self):
-        self.st = side_stream(self.dev)
-        self.st.wait_stream(torch.cuda.current_stream())
-        _pending.append(self.keep)
-        self.ctx = torch.cuda.stream(self.st)
-        self.ctx.__enter__()
-        return self
-
-    def __exit__(self, *exc):
-        return self.ctx.__exit__(*exc)
-
-
-# MI355_WGRAD_DEFER=1 (experiment): weight gradients are not launched where autograd reaches them but collected and issued
-# in batches on the side stream -- one fork per batch (at the stage boundaries of the backward, DAStep._on_stage_grad)
-# instead of one per layer -- so that they run beside the dgrad / BatchNorm-backward chain of the next stage.
-DEFER_WGRAD = _os.environ.get('MI355_WGRAD_DEFER', '0') == '1'
-_deferred = []
-
-
-def defer_wgrad(fn, keep):
-    _deferred.append((fn, keep))
-
-
-def flush_wgrads(device=None):
-    """Issue the collected weight-gradient launches on the side stream (ordered after everything enqueued so far)."""
-    if not _deferred:
-        return
-    dev = device if device is not None else _deferred[0][1][0].device
-    with on_side(dev, keep=tuple(t for _, keep in _deferred for t in keep)):
-        for fn, _ in _deferred:
-            fn()
-    del _deferred[:]
-
 
 # ---------------------------------------------------------------- grouped weight gradients
 # Inside `with grouped_wgrads():` (the training step wraps each forward+backward in it) the conv layers do not launch their
@@ -351,10 +282,10 @@ def flush_wgrads(device=None):
 # -- at the stage boundaries of the backward (DAStep._on_stage_grad) and when the block ends -- so that the many small
 # layers of a ResNet stage share one launch.  Outside such a block every weight gradient is launched immediately
 # (a caller may read param.grad right after backward()).
+# (Weight gradients on a side stream -- per layer, collected per stage, or the grouped launch -- were measured slower in every
+#  form, rounds 1-3: each fork / join inside the captured graphs costs more than the overlap returns; DESIGN.md section 7.  That
+#  machinery is gone; weight gradients run on the stream of the backward pass.)
 GROUP_WGRAD = _os.environ.get('MI355_WGRAD_GROUP', '1') == '1'
-# experiment (measured slower: 34.84 vs 34.27 / 34.47 ms on one box): the grouped launch goes to the side stream and runs
-# beside the next stage's dgrad / BatchNorm chain
-GROUP_WGRAD_SIDE = int(_os.environ.get('MI355_WGRAD_GROUP_SIDE', '0'))
 _group_depth = 0
 _group_items = []
 
@@ -388,11 +319,7 @@ def flush_grouped_wgrads():
     from . import ops
     items = list(_group_items)
     del _group_items[:]
-    if GROUP_WGRAD_SIDE:
-        with on_side(items[0][1].device, keep=tuple(t for it in items for t in (it[1], it[2]))):
-            ops.conv_wgrad_grouped(items, ws_tag='side')
-    else:
-        ops.conv_wgrad_grouped(items)
+    ops.conv_wgrad_grouped(items)
 
 
 # ---------------------------------------------------------------- unit gradient of a total loss
@@ -415,10 +342,5 @@ def is_unit_grad(g):
 
 
 def join_side():
-    """Current stream waits for all side-stream work; releases the tensors kept alive for it."""
+    """Everything a backward pass has deferred is enqueued: the weight gradients still waiting for their grouped launch."""
     flush_grouped_wgrads()
-    flush_wgrads()
-    if _pending:
-        for st in _side.values():
-            torch.cuda.current_stream().wait_stream(st)
-        _pending.clear()

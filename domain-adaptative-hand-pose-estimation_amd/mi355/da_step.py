@@ -167,14 +167,12 @@ class DAStep:
 
     def _on_stage_grad(self, stage):
         _rt.flush_grouped_wgrads()       # the weight gradients of the stage just finished: one grouped launch
-        if _rt.DEFER_WGRAD:
-            _rt.flush_wgrads()           # the weight gradients collected behind this tensor start on the side stream now
         if self._reducer is not None:
             self._reducer.stage_done(stage)
 
     def _begin_reduce(self, keys):
-        """Arm the overlapped reducer for the backward about to run (eager, more than one rank, no side-stream wgrads)."""
-        self._reducer = _OverlapReducer(self, keys) if (self.overlap and _distributed() and not _rt.SIDE_WGRAD and
+        """Arm the overlapped reducer for the backward about to run (eager, more than one rank)."""
+        self._reducer = _OverlapReducer(self, keys) if (self.overlap and _distributed() and
                                                          not torch.cuda.is_current_stream_capturing()) else None
         if self._reducer is not None:
             # collectives will run beside this backward: the one-launch BatchNorm backward needs every CU for its resident

@@ -585,13 +585,8 @@ class _DeconvFn(torch.autograd.Function):
             g, acc = grad_slot(weight)
             if _rt.grouping_wgrads():
                 _rt.group_wgrad(desc, dy, x, g, acc)
-            elif _rt.DEFER_WGRAD:
-                _rt.defer_wgrad(lambda: ops.conv_wgrad(desc, dy, x, g, acc, ws_tag='side'), (x, dy))
-            elif _rt.side_wgrad_for(desc):
-                with _rt.on_side(x.device, keep=(x, dy)):
-                    ops.conv_wgrad(desc, dy, x, g, acc, ws_tag='side')      # conv-form input = dy, conv-form output = x
             else:
-                ops.conv_wgrad(desc, dy, x, g, acc)
+                ops.conv_wgrad(desc, dy, x, g, acc)      # conv-form input = dy, conv-form output = x
         if ctx.needs_input_grad[0] and ctx.fp8:
             _, _, wf8, _, sw = mod._plan_fp8(x)
             dy8, sdy = mod._q_dy.quantize(dy)
@@ -1023,11 +1018,6 @@ class Conv2d(_FastSlots, nn.Module):
         if desc.Ci == self.in_channels:
             if _rt.grouping_wgrads():
                 _rt.group_wgrad(desc, x, dy, g, acc)
-            elif _rt.DEFER_WGRAD:
-                _rt.defer_wgrad(lambda: ops.conv_wgrad(desc, x, dy, g, acc, ws_tag='side'), (x, dy))
-            elif _rt.side_wgrad_for(desc):
-                with _rt.on_side(x.device, keep=(x, dy)):
-                    ops.conv_wgrad(desc, x, dy, g, acc, ws_tag='side')
             else:
                 ops.conv_wgrad(desc, x, dy, g, acc)
         else:   # stem: kernel works on the padded channel count; un-pad into the (Co,3,7,7) gradient

@@ -37,19 +37,20 @@ def test_library_exports_every_header_symbol(lib_path):
 
 
 def test_isa_gate_on_the_shipped_library(lib_path):
-    """build.py's gate: the linked library holds no packed-fp32 arithmetic whose op_sel takes a low result from a high
-    register (the instruction form behind the round-2 dropped-addend fault) -- and the gate itself
-    recognises such an instruction when it sees one."""
+    """build.py's gate: the linked library holds no packed-fp32 arithmetic (any VOP3P v_pk_*_f32 opcode) that takes an operand
+    half from the other register of its pair (the instruction form behind the round-2 dropped-addend fault, DESIGN.md
+    section 7) -- and the gate itself recognises such instructions when it sees them."""
     import importlib.util
     spec = importlib.util.spec_from_file_location('mi355_build', os.path.join(PKG, 'build.py'))
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     assert mod.isa_gate(lib_path) > 100000                   # every device instruction of the library was inspected
-    bad = 'v_pk_add_f32 v[4:5], v[4:5], v[22:23] op_sel:[0,1] op_sel_hi:[1,0]'
-    ok = ['v_pk_add_f32 v[4:5], v[4:5], v[22:23]', 'v_pk_mul_f32 v[2:3], v[2:3], v[8:9] op_sel_hi:[0,1]',
-          'v_pk_mov_b32 v[22:23], v[22:23], v[22:23] op_sel:[1,0]']
-    hit = lambda ins: bool(mod._PK.search(ins) and mod._OPSEL.search(ins) and '1' in mod._OPSEL.search(ins).group(1))
-    assert hit(bad) and not any(hit(i) for i in ok)
+    bad = ['v_pk_add_f32 v[4:5], v[4:5], v[22:23] op_sel:[0,1] op_sel_hi:[1,0]',      # the round-2 fault
+           'v_pk_mul_f32 v[2:3], v[2:3], v[8:9] op_sel_hi:[0,1]', 'v_pk_fma_f32 v[0:1], v[2:3], v[4:5], v[6:7] op_sel:[1,0,0]',
+           'v_pk_max_f32 v[0:1], v[2:3], v[4:5] op_sel_hi:[1,0]']                          # any VOP3P fp32-pair opcode
+    ok = ['v_pk_add_f32 v[4:5], v[4:5], v[22:23]', 'v_pk_fma_f32 v[0:1], v[2:3], v[4:5], v[6:7] op_sel_hi:[1,1,1]',
+          'v_pk_mov_b32 v[22:23], v[22:23], v[22:23] op_sel:[1,0]', 'v_pk_add_f16 v1, v2, v3 op_sel:[1,0]']
+    assert all(mod.swaps_halves(i) for i in bad) and not any(mod.swaps_halves(i) for i in ok)
     assert '-fno-slp-vectorize' in mod.FLAGS
 
 
