@@ -810,19 +810,20 @@ struct WgradKwArgs {
 // 128-byte rows, tr16-read friendly for any 4 consecutive rows (shifted reads included)
 __device__ __forceinline__ int swzx(int r, int ch) { return r * 128 + ((ch ^ (((r >> 1) & 1) << 2)) << 4); }
 
+template <int MT> struct WgradKwSmem { static constexpr int kBytes = 64 * 256 + (64 + 4 * 8 + 4) * 128 + 2 * 64 * 4; };
+// body shared by the single-problem kernel and the grouped one (`bid` of `nblk` blocks work on problem p)
 template <int MT>
-__global__ __launch_bounds__(256, 3) void wgrad_kw_kernel(const WgradKwArgs p) {
+__device__ __forceinline__ void wgrad_kw_body(const WgradKwArgs& p, const int bid, const int nblk, char* smem) {
   constexpr int BO = 64 * MT, BKM = 64;
   constexpr int CPRY = BO / 8, RPY = 256 / CPRY, NPY = BKM / RPY;
   constexpr int XROWS = 64 + 4 * 8 + 4;
-  __shared__ __attribute__((aligned(16))) char smem[BKM * 256 + XROWS * 128 + 2 * BKM * 4];
   char* ys = smem;
   char* xs = smem + BKM * 256;
   int* rowinfo = reinterpret_cast<int*>(smem + BKM * 256 + XROWS * 128);   // [2][BKM]: image row oy of each pixel
 
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int ntile = p.nto * 3 * p.nci;
-  const int lid = xcd_remap(blockIdx.x, gridDim.x);
+  const int lid = xcd_remap(bid, nblk);
   const int split = lid / ntile;
   int tile = lid - split * ntile;
   const int ot = tile / (3 * p.nci); tile -= ot * 3 * p.nci;
@@ -947,6 +948,25 @@ __global__ __launch_bounds__(256, 3) void wgrad_kw_kernel(const WgradKwArgs p) {
         const int c = ci0 + wn0 + r31;
         if (o < p.Co && c < p.Ci) out[(size_t)o * p.ldw + (kh * 3 + k) * p.Ci + c] = acc[k][i][r];
       }
+}
+template <int MT>
+__global__ __launch_bounds__(256, 3) void wgrad_kw_kernel(const WgradKwArgs p) {
+  __shared__ __attribute__((aligned(16))) char smem[WgradKwSmem<MT>::kBytes];
+  wgrad_kw_body<MT>(p, (int)blockIdx.x, (int)gridDim.x, smem);
+}
+// The 3x3 / stride-1 weight gradients of one ResNet stage in ONE launch (bf16).  Alone, such a layer offers 24 .. 48 output tiles:
+// it splits its pixel range 16 .. 256 ways to reach a few hundred blocks, which then sit unevenly on the 256 CUs (384 blocks:
+// half the CUs carry two), run 8 .. 16 K steps each (mostly prologue and fp32 slab stores) and leave 16 .. 256 slabs to a reduce
+// launch of their own.  Grouped, the tiles of all the stage's layers fill the chip together with a few long splits per layer and
+// one grouped slab reduction.  Argument blocks by value in the kernel-argument segment (graph-capturable), as wgrad_group_kernel.
+#define WGK_MAX 16
+struct WgradKwGroupArgs { WgradKwArgs p[WGK_MAX]; int bstart[WGK_MAX + 1]; int n; };
+template <int MT>
+__global__ __launch_bounds__(256, 3) void wgrad_kw_group_kernel(const WgradKwGroupArgs g) {
+  __shared__ __attribute__((aligned(16))) char smem[WgradKwSmem<MT>::kBytes];
+  int i = 0;
+  while (i + 1 < g.n && (int)blockIdx.x >= g.bstart[i + 1]) ++i;         // block-uniform scan of <= 16 entries
+  wgrad_kw_body<MT>(g.p[i], (int)blockIdx.x - g.bstart[i], g.bstart[i + 1] - g.bstart[i], smem);
 }
 
 // ------------------------------------------------------------------------------------ wgrad, 3x3 / 4x4 stride 2 pad 1 (bf16)
@@ -1721,27 +1741,126 @@ static long group_plan(const mi355_wgrad_item* items, const int* idx, int n, Gro
   if (ws_bytes) *ws_bytes = off;
   return blocks;
 }
+// 3x3 / stride-1 problems (wgrad_kw_kernel) small enough to share a launch: fewer than 24 K steps per block at 768 blocks
+static bool kw_group_eligible(const mi355_conv_desc* d, const WgradPlan& w) {
+  static const bool on = !(getenv("MI355_WGRAD_KW_GROUP") && atoi(getenv("MI355_WGRAD_KW_GROUP")) == 0);      // A/B switch
+  if (!on || !w.kw3) return false;
+  const long M = (long)d->N * d->Ho * d->Wo, ksteps = (M + 63) / 64;
+  return (long)w.nto * 3 * w.nti * ksteps < 768L * 24;
+}
+static long kw_group_plan(const mi355_wgrad_item* items, const int* idx, int n, GroupPlan* gp, size_t* ws_bytes) {
+  double W = 0;
+  for (int k = 0; k < n; ++k) {
+    const mi355_conv_desc* d = &items[idx[k]].d; WgradPlan w = plan_wgrad(d);
+    W += (double)w.nto * 3 * w.nti * (((long)d->N * d->Ho * d->Wo + 63) / 64);
+  }
+  static const int group_blocks = getenv("MI355_WG_KW_GROUP_BLOCKS") ? atoi(getenv("MI355_WG_KW_GROUP_BLOCKS")) : 768;
+  long per = (long)(W / group_blocks) + 1; if (per < 16) per = 16;
+  long blocks = 0; size_t off = 0;
+  for (int k = 0; k < n; ++k) {
+    const mi355_wgrad_item& it = items[idx[k]]; const mi355_conv_desc* d = &it.d; WgradPlan w = plan_wgrad(d);
+    const long M = (long)d->N * d->Ho * d->Wo, ksteps = (M + 63) / 64;
+    long S = (ksteps + per - 1) / per; if (S < 1) S = 1;
+    long rps = (M + S - 1) / S; rps = ((rps + 63) / 64) * 64;
+    S = (M + rps - 1) / rps;
+    gp[k].S = (int)S; gp[k].rps = (int)rps; gp[k].ws_off = off;
+    if (S > 1 || it.accumulate) off += (size_t)S * d->Co * w.ldw * sizeof(float);
+    blocks += (long)w.nto * 3 * w.nti * S;
+  }
+  if (ws_bytes) *ws_bytes = off;
+  return blocks;
+}
+static int launch_wgrad_kw_group(const mi355_wgrad_item* items, const int* idx, int n, void* ws, size_t ws_bytes, hipStream_t st) {
+  GroupPlan gp[WGK_MAX]; size_t need = 0;
+  kw_group_plan(items, idx, n, gp, &need);
+  if (need && (!ws || ws_bytes < need)) MI_FAIL(MI355_EWORKSPACE, "wgrad kw group workspace %zu < %zu", ws_bytes, need);
+  WgradKwGroupArgs g; memset(&g, 0, sizeof(g));
+  SlabGroupArgs sg; memset(&sg, 0, sizeof(sg));
+  int nb = 0, nsb = 0;
+  double flops = 0, bytes = 0;
+  const int mt = plan_wgrad(&items[idx[0]].d).mt;
+  for (int k = 0; k < n; ++k) {
+    const mi355_wgrad_item& it = items[idx[k]]; const mi355_conv_desc* d = &it.d;
+    WgradPlan w = plan_wgrad(d);
+    const bool direct = gp[k].S == 1 && !it.accumulate;
+    WgradKwArgs& a = g.p[k];
+    a.X = it.x; a.DY = it.dy; a.out = direct ? it.dw : reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + gp[k].ws_off);
+    a.H = d->Hi; a.W = d->Wi; a.Ci = d->Ci; a.Co = d->Co;
+    a.lwf = ilog2_exact(d->Wi); a.lw = a.lwf > 6 ? 6 : a.lwf; a.halo = d->Wi > 64;
+    a.M = d->N * d->Ho * d->Wo; a.rows_per_split = gp[k].rps; a.ldw = w.ldw;
+    a.slab_stride = (long)d->Co * w.ldw; a.nto = w.nto; a.nci = w.nti;
+    a.x_bytes = (unsigned)((long)d->N * d->Hi * d->Wi * d->Ci * 2); a.dy_bytes = (unsigned)((long)a.M * d->Co * 2);
+    a.dH = make_fastdiv(d->Hi);
+    g.bstart[k] = nb; nb += w.nto * 3 * w.nti * gp[k].S;
+    flops += 2.0 * a.M * (double)d->Co * w.ldw; bytes += (double)a.x_bytes + a.dy_bytes + 4.0 * d->Co * w.ldw;
+    if (!direct) {
+      SlabItem& q = sg.it[sg.n];
+      q.slabs = a.out; q.out = it.dw; q.n4 = a.slab_stride / 4; q.stride = a.slab_stride; q.S = gp[k].S; q.accumulate = it.accumulate;
+      sg.bstart[sg.n] = nsb; nsb += cdiv(q.n4, 256); ++sg.n;
+    }
+  }
+  g.bstart[n] = nb; g.n = n; sg.bstart[sg.n] = nsb;
+  {
+    if (prof_on()) {
+      const mi355_conv_desc* d0 = &items[idx[0]].d;
+      prof_set_tag("wgrad_kw_group x%d blocks%d first k%ds%d %d>%d @%dx%d", n, nb, d0->kh, d0->stride, d0->Ci, d0->Co, d0->Hi, d0->Wi);
+    }
+    ProfScope ps(st, flops, bytes);
+    if (mt == 1) hipLaunchKernelGGL(wgrad_kw_group_kernel<1>, dim3(nb), dim3(256), 0, st, g);
+    else hipLaunchKernelGGL(wgrad_kw_group_kernel<2>, dim3(nb), dim3(256), 0, st, g);
+    MI_CHECK_LAUNCH("wgrad_kw_group");
+  }
+  if (sg.n) {
+    double sb = 0; for (int k = 0; k < sg.n; ++k) sb += 16.0 * sg.it[k].n4 * (sg.it[k].S + 1);
+    char lab[64];
+    if (prof_on()) snprintf(lab, sizeof(lab), "slab_reduce_group x%d", sg.n);
+    ProfScope ps(st, 0.0, sb, 2, prof_on() ? lab : nullptr);
+    hipLaunchKernelGGL(slab_reduce_group_kernel, dim3(nsb), dim3(256), 0, st, sg); MI_CHECK_LAUNCH("slab_reduce_group");
+  }
+  return MI355_OK;
+}
+// The launches mi355_conv_wgrad_grouped makes of `items`, in order, handed to `fn(kind, idx, m)`: kind 0 = one item through
+// mi355_conv_wgrad, 1 = a group of the generic kernel, 2 = a group of the 3x3 / stride-1 kernel.  One walk for the launcher and
+// for the workspace size, so the two cannot disagree.  Two items that write the same dw (one conv used twice in a backward:
+// overwrite, then accumulate) must neither share a launch -- the overwrite and the read-modify-write would race -- nor change
+// their order: whatever is pending goes first.
+template <typename F>
+static int walk_wgrad_groups(const mi355_wgrad_item* items, int n, F&& fn) {
+  int gi[WG_MAX], ki[WGK_MAX]; int gm = 0, km = 0;
+  auto flush_g = [&]() -> int { if (!gm) return 0; int e = fn(1, gi, gm); gm = 0; return e; };
+  auto flush_k = [&]() -> int { if (!km) return 0; int e = fn(2, ki, km); km = 0; return e; };
+  for (int i = 0; i < n; ++i) {
+    const mi355_wgrad_item& it = items[i];
+    WgradPlan w = plan_wgrad(&it.d);
+    bool shares = false;
+    for (int k = 0; k < gm; ++k) shares = shares || items[gi[k]].dw == it.dw;
+    for (int k = 0; k < km; ++k) shares = shares || items[ki[k]].dw == it.dw;
+    if (shares) { if (int e = flush_g()) return e; if (int e = flush_k()) return e; }
+    if (kw_group_eligible(&it.d, w)) {
+      if (km && (km == WGK_MAX || plan_wgrad(&items[ki[0]].d).mt != w.mt)) { if (int e = flush_k()) return e; }
+      ki[km++] = i;
+    } else if (group_eligible(&it.d, w)) {
+      if (gm && (gm == WG_MAX || items[gi[0]].d.dtype != it.d.dtype)) { if (int e = flush_g()) return e; }
+      gi[gm++] = i;
+    } else {
+      int one = i;
+      if (int e = fn(0, &one, 1)) return e;
+    }
+  }
+  if (int e = flush_g()) return e;
+  return flush_k();
+}
 extern "C" size_t mi355_conv_wgrad_grouped_workspace(const mi355_wgrad_item* items, int n) {
   if (!items || n < 1) return 0;
   size_t need = 0;
-  int idx[WG_MAX]; int m = 0; GroupPlan gp[WG_MAX];
-  for (int i = 0; i <= n; ++i) {
-    bool flush = (i == n) || m == WG_MAX;
-    if (i < n) {
-      WgradPlan w = plan_wgrad(&items[i].d);
-      bool shares = false;       // (same grouping as mi355_conv_wgrad_grouped: an item whose dw is already pending closes the group)
-      for (int k = 0; k < m; ++k) shares = shares || items[idx[k]].dw == items[i].dw;
-      if (!group_eligible(&items[i].d, w)) {
-        size_t b = mi355_conv_wgrad_workspace(&items[i].d); if (b > need) need = b;
-        if (!shares) continue;
-        flush = true;
-      }
-      if (m && (items[idx[0]].d.dtype != items[i].d.dtype || shares)) flush = true;
-    }
-    if (flush && m) { size_t b = 0; group_plan(items, idx, m, gp, &b); if (b > need) need = b; m = 0; }
-    if (i < n && group_eligible(&items[i].d, plan_wgrad(&items[i].d))) idx[m++] = i;
-  }
-  if (m) { size_t b = 0; group_plan(items, idx, m, gp, &b); if (b > need) need = b; }
+  (void)walk_wgrad_groups(items, n, [&](int kind, const int* idx, int m) -> int {
+    size_t b = 0;
+    if (kind == 0) b = mi355_conv_wgrad_workspace(&items[idx[0]].d);
+    else if (kind == 1) { GroupPlan gp[WG_MAX]; group_plan(items, idx, m, gp, &b); }
+    else { GroupPlan gp[WGK_MAX]; kw_group_plan(items, idx, m, gp, &b); }
+    if (b > need) need = b;
+    return 0;
+  });
   return need;
 }
 static int launch_wgrad_group(const mi355_wgrad_item* items, const int* idx, int n, void* ws, size_t ws_bytes, hipStream_t st) {
@@ -1801,26 +1920,15 @@ static int launch_wgrad_group(const mi355_wgrad_item* items, const int* idx, int
 extern "C" int mi355_conv_wgrad_grouped(const mi355_wgrad_item* items, int n, void* ws, size_t ws_bytes, void* stream) {
   if (!items || n < 1) MI_FAIL(MI355_EINVAL, "wgrad_grouped: no items");
   hipStream_t st = as_stream(stream);
-  int idx[WG_MAX]; int m = 0;
   for (int i = 0; i < n; ++i) {
-    const mi355_wgrad_item& it = items[i];
-    if (int e = check_desc(&it.d)) return e;
-    if (!it.x || !it.dy || !it.dw) MI_FAIL(MI355_EINVAL, "wgrad_grouped: item %d has a null operand", i);
-    WgradPlan w = plan_wgrad(&it.d);
-    // Two items that write the same dw (one conv used twice in a backward: overwrite, then accumulate) must neither share a
-    // launch -- the overwrite and the read-modify-write would race -- nor change their order: whatever is pending goes first.
-    bool shares = false;
-    for (int k = 0; k < m; ++k) shares = shares || items[idx[k]].dw == it.dw;
-    if (shares) { if (int e = launch_wgrad_group(items, idx, m, ws, ws_bytes, st)) return e; m = 0; }
-    if (!group_eligible(&it.d, w)) {
-      if (int e = mi355_conv_wgrad(&it.d, it.x, it.dy, it.dw, it.accumulate, ws, ws_bytes, stream)) return e;
-      continue;
-    }
-    if (m && (m == WG_MAX || items[idx[0]].d.dtype != it.d.dtype)) { if (int e = launch_wgrad_group(items, idx, m, ws, ws_bytes, st)) return e; m = 0; }
-    idx[m++] = i;
+    if (int e = check_desc(&items[i].d)) return e;
+    if (!items[i].x || !items[i].dy || !items[i].dw) MI_FAIL(MI355_EINVAL, "wgrad_grouped: item %d has a null operand", i);
   }
-  if (m) { if (int e = launch_wgrad_group(items, idx, m, ws, ws_bytes, st)) return e; }
-  return MI355_OK;
+  return walk_wgrad_groups(items, n, [&](int kind, const int* idx, int m) -> int {
+    if (kind == 0) { const mi355_wgrad_item& it = items[idx[0]]; return mi355_conv_wgrad(&it.d, it.x, it.dy, it.dw, it.accumulate, ws, ws_bytes, stream); }
+    if (kind == 1) return launch_wgrad_group(items, idx, m, ws, ws_bytes, st);
+    return launch_wgrad_kw_group(items, idx, m, ws, ws_bytes, st);
+  });
 }
 
 // ------------------------------------------------------------------------------------ weight packing

@@ -975,6 +975,43 @@ def test_grouped_weight_gradients_of_a_resnet_stage_at_full_size(gpu):
         assert float((dw - ref).abs().max()) <= 2e-3 * float(ref.abs().max()), (i, shapes[i])
 
 
+def test_grouped_3x3_weight_gradients_of_resnet_stages_at_full_size(gpu):
+    """The 3x3 / stride-1 weight gradients of a ResNet stage in one wgrad_kw_group launch (B=64, bf16): layer3's six 256 -> 256
+    @16x16, layer1's 64 -> 64 @64x64 (one output-channel tile: its own group), layer4's 512 -> 512 @8x8, layer2's 128 -> 128 @32x32,
+    with accumulating items and an item that writes the gradient of an earlier one -- against mi355_conv_wgrad problem by problem,
+    and two runs bit for bit."""
+    ops = _ops()
+    tdt = torch.bfloat16
+    shapes = [(64, 16, 16, 256, 256)] * 6 + [(64, 64, 64, 64, 64)] * 3 + [(64, 8, 8, 512, 512)] * 2 + [(64, 32, 32, 128, 128)] * 3
+    items, refs, bases = [], [], []
+    for i, (N, H, W, Ci, Co) in enumerate(shapes):
+        d = ops.make_desc(N, H, W, Ci, Co, 3, 3, 1, 1, tdt)
+        x = ops.nhwc_empty(N, Ci, H, W, tdt, gpu).normal_()
+        dy = ops.nhwc_empty(N, Co, H, W, tdt, gpu).normal_()
+        acc = (i % 4 == 1)
+        base = torch.randn(Co * 9 * Ci, device=gpu) if acc else None
+        ref = base.clone() if acc else torch.empty(Co * 9 * Ci, device=gpu)
+        ops.conv_wgrad(d, x, dy, ref, acc)
+        items.append((d, x, dy, torch.empty(Co * 9 * Ci, device=gpu), acc)); refs.append(ref); bases.append(base)
+    # the first layer3 conv once more, accumulating onto its own gradient (overwrite, then accumulate: the order must hold)
+    d0, x0, dy0, dw0, _ = items[0]
+    x0b, dy0b = torch.randn_like(x0), torch.randn_like(dy0)
+    ops.conv_wgrad(d0, x0b, dy0b, refs[0], True)
+    items.append((d0, x0b, dy0b, dw0, True))
+    outs = []
+    for _ in range(2):
+        for (d, x, dy, dw, acc), base in zip(items[:-1], bases):
+            dw.copy_(base) if acc else dw.fill_(float('nan'))
+        ops.conv_wgrad_grouped(items)
+        torch.cuda.synchronize()
+        outs.append([it[3].clone() for it in items[:-1]])
+    for i, (dw, ref) in enumerate(zip(outs[0], refs)):
+        assert torch.isfinite(dw).all(), i
+        assert float((dw - ref).abs().max()) <= 2e-4 * float(ref.abs().max()), (i, shapes[i])
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+
+
 def test_grouped_weight_gradients_keep_the_order_of_items_that_share_a_gradient(gpu):
     """One conv used twice in a backward hands the group two items with the SAME dw (overwrite, then accumulate): they must not
     share a launch (the overwrite and the read-modify-write would race) and must keep their order (advisor, round 2)."""
