@@ -37,21 +37,32 @@ struct GatherSmem {
 //      (same construction as wgrad_kw_kernel).
 // CAT: one more K tile behind the conv's own taps, gathered from a second operand pair (A2 [M][c2] at the output resolution,
 //      B2 [Nout][c2]; channels c2 .. BK-1 of that tile are out-of-range lanes = zeros): y = conv(x, w) + A2 * B2^T as ONE GEMM.
+// KG: K groups inside the workgroup (intra-workgroup split-K; LDS-DMA builds).  A launch that offers one tile per CU or fewer runs
+//      one wave per SIMD, and its K loop is a chain of exposed load latencies (one tile in flight per CU).  With KG = 2 the block has
+//      2 x WGM x WGN waves: group g multiplies its half of the K tiles out of a ring of its own (two tiles in flight per CU, two
+//      waves per SIMD), group 1 then hands its accumulators to group 0 through LDS (fp32, its own ring's space) and group 0 runs
+//      the usual epilogue -- streamed out by all the block's threads.  No fp32 partials in HBM.
 template <typename T, int BM, int BN, bool SMALL_C, int WGM = 2, int WGN = 2, bool HM_OUT = false, bool DMA = false, int EPI = 0,
-          bool KW3 = false, bool CAT = false>
-__global__ __launch_bounds__(64 * WGM * WGN, (KW3 && BM == 256) ? 2 : 1) void gather_gemm_kernel(const GatherArgs p) {
+          bool KW3 = false, bool CAT = false, int KG = 1>
+__global__ __launch_bounds__(64 * WGM * WGN * KG, (KW3 && BM == 256) ? 2 : 1) void gather_gemm_kernel(const GatherArgs p) {
   constexpr int CH = MmaTraits<T>::CH;
-  constexpr int NTHR = 64 * WGM * WGN, RPP = NTHR / 8;      // rows staged per pass (8 lanes = one 128-byte row)
+  constexpr int GTHR = 64 * WGM * WGN;                          // threads of one K group (= the whole block unless KG > 1)
+  constexpr int NTHR = GTHR * KG, RPP = GTHR / 8;               // rows staged per pass (8 lanes = one 128-byte row)
   constexpr int WM = BM / WGM, WN = BN / WGN, MT = WM / 32, NT = WN / 32;
   constexpr int RA = BM / RPP, RB = BN / RPP;
   using SM = GatherSmem<T, BM, BN, DMA ? 2 : 1, KW3>;
   static_assert(!KW3 || (!DMA && !SMALL_C && !HM_OUT && sizeof(T) == 2), "KW3 is a bf16 variant of the plain large-channel kernel");
   static_assert(!DMA || !SMALL_C, "the LDS-DMA pipeline is built for the large-channel path");
   static_assert(!CAT || (!SMALL_C && !HM_OUT && !KW3 && EPI != 2), "CAT: plain large-channel forward (register-staged or LDS-DMA)");
+  static_assert(KG == 1 || (KG == 2 && DMA && !CAT && !HM_OUT && EPI != 2 && BM * BN * 4 <= 2 * SM::kStage), "KG: two K groups on the LDS-DMA ring");
+  constexpr int kRing = 2 * SM::kStage;                         // (KG > 1) LDS of one K group's ring; group g's ring starts at g * kRing
+  constexpr int kTotal = SM::kBytes + (KG - 1) * kRing;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  int* row_off = reinterpret_cast<int*>(smem + SM::kBytes - BM * 4);
+  int* row_off = reinterpret_cast<int*>(smem + kTotal - BM * 4);
 
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int t = threadIdx.x, lane = t & 63;
+  const int tg = KG > 1 ? t % GTHR : t, grp = KG > 1 ? __builtin_amdgcn_readfirstlane(t / GTHR) : 0;      // thread in its K group, K group
+  const int wave = tg >> 6, wave_blk = t >> 6;                  // wave in its K group (sub-tile, staging), wave in the block (statistics fold)
   const int tile_g = xcd_remap(blockIdx.x, p.ntiles);
   const int phi = tile_g % p.nphase, tile = tile_g / p.nphase;
   const Phase& P = p.ph[phi];
@@ -60,7 +71,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, (KW3 && BM == 256) ? 2 : 1) void ga
   const Tap* __restrict__ ptaps = p.taps + P.tap0;
   const int m0 = (tile / p.ntn) * BM, n0 = (tile % p.ntn) * BN;
   const int wm0 = (wave / WGN) * WM, wn0 = (wave % WGN) * WN;
-  const int lc = t & 7, lr = t >> 3;
+  const int lc = tg & 7, lr = tg >> 3;
 
   const __amdgpu_buffer_rsrc_t rsA = make_rsrc(p.A, p.a_bytes), rsB = make_rsrc(p.B, p.b_bytes);
   const __amdgpu_buffer_rsrc_t rsA2 = make_rsrc(CAT ? p.A2 : p.A, CAT ? p.a2_bytes : 0u), rsB2 = make_rsrc(CAT ? p.B2 : p.B, CAT ? p.b2_bytes : 0u);
@@ -160,7 +171,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, (KW3 && BM == 256) ? 2 : 1) void ga
     (void)koff; (void)toff; (void)wave_u;   // (only used in the device pass below)
 #if defined(__HIP_DEVICE_COMPILE__)    // (the host pass must still be able to emit the kernel stub)
     typedef __attribute__((address_space(3))) void* ldsp;
-    char* sa = smem + stage * SM::kStage + wave_u * 1024;
+    char* sa = smem + grp * kRing + stage * SM::kStage + wave_u * 1024;
     char* sb = sa + BM * 128;
     if constexpr (CAT) {
       if (cat) {                                      // logical chunk lcs of row m / output channel n of the second operand pair
@@ -315,6 +326,51 @@ __global__ __launch_bounds__(64 * WGM * WGN, (KW3 && BM == 256) ? 2 : 1) void ga
       __builtin_amdgcn_s_setprio(0);
       if (++kw == 3) { kw = 0; ++g; }
     }
+  } else if constexpr (DMA && KG > 1) {
+    // K group g multiplies K tiles [kbeg, kend) out of its own ring; the barriers are the block's, so both groups make nk0 trips
+    const int nk0 = (nk + 1) >> 1;
+    const int kbeg = grp ? nk0 : 0, kend = grp ? nk : nk0;
+    char* ring = smem + grp * kRing;
+    if (kbeg < kend) dma_tile(kbeg, 0);
+    for (int i = 0; i < nk0; ++i) {
+      const int kt = kbeg + i;
+#if defined(__HIP_DEVICE_COMPILE__)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+      __syncthreads();
+      if (kt + 1 < kend) dma_tile(kt + 1, (i + 1) & 1);
+      as = ring + (i & 1) * SM::kStage; bs = as + BM * 128;
+      if (kt < kend) {
+        __builtin_amdgcn_s_setprio(1);
+        compute();
+        __builtin_amdgcn_s_setprio(0);
+      }
+    }
+    // group 1's partial sums travel to group 0 through group 1's ring space: [wave][accumulator quad][lane] float4, written and
+    // read by the same (wave, lane) pair of each group -- conflict-free, no index arithmetic beyond a constant stride
+    __syncthreads();
+    float4* red = reinterpret_cast<float4*>(smem + kRing) + wave * (MT * NT * 4 * 64) + lane;
+    if (grp == 1) {
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            red[((i * NT + j) * 4 + q) * 64] = make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
+    }
+    __syncthreads();
+    if (grp == 0) {
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const float4 v = red[((i * NT + j) * 4 + q) * 64];
+            acc[i][j][4 * q] += v.x; acc[i][j][4 * q + 1] += v.y; acc[i][j][4 * q + 2] += v.z; acc[i][j][4 * q + 3] += v.w;
+          }
+    }
   } else if constexpr (DMA) {
     dma_tile(0, 0);
     for (int kt = 0; kt < nk; ++kt) {
@@ -375,6 +431,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, (KW3 && BM == 256) ? 2 : 1) void ga
   }
   // ---- epilogue: (acc + bias) * scale -> T -> LDS tile -> coalesced 16-byte rows (+residual / +dx)
   const float scale = p.scale ? *p.scale : 1.0f;
+  if (KG == 1 || grp == 0)       // (KG > 1: K group 0 holds the sums; every thread of the block then streams rows out)
 #pragma unroll
   for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -520,7 +577,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, (KW3 && BM == 256) ? 2 : 1) void ga
     if (lane < CPR) {
 #pragma unroll
       for (int e = 0; e < CH; ++e) {
-        float* q = sp + ((size_t)wave * BN + (t % CPR) * CH + e) * 2;
+        float* q = sp + ((size_t)wave_blk * BN + (t % CPR) * CH + e) * 2;
         q[0] = smean[e]; q[1] = sm2[e];
       }
     }
@@ -558,7 +615,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, (KW3 && BM == 256) ? 2 : 1) void ga
       const int c = t % CPR;
 #pragma unroll
       for (int e = 0; e < CH; ++e) {
-        float* q = sp + ((size_t)wave * BN + c * CH + e) * 3;
+        float* q = sp + ((size_t)wave_blk * BN + c * CH + e) * 3;
         q[0] = sn; q[1] = smean[e]; q[2] = sm2[e];
       }
     }
@@ -1193,16 +1250,17 @@ __global__ void zero_fill_kernel(uint4* __restrict__ p, size_t n16) {
 // ------------------------------------------------------------------------------------ host side
 static int ilog2_exact(int v) { int s = 0; while ((1 << s) < v) ++s; return ((1 << s) == v) ? s : -1; }
 
-template <typename T, int BM, int BN, bool SMALL_C, int WGM, int WGN, bool HM_OUT, bool DMA, int EPI, bool KW3 = false, bool CAT = false>
+template <typename T, int BM, int BN, bool SMALL_C, int WGM, int WGN, bool HM_OUT, bool DMA, int EPI, bool KW3 = false, bool CAT = false, int KG = 1>
 static void launch_gather_epi(const GatherArgs& a, hipStream_t st) {
-  constexpr int smem = GatherSmem<T, BM, BN, DMA ? 2 : 1, KW3>::kBytes;
-  auto kern = gather_gemm_kernel<T, BM, BN, SMALL_C, WGM, WGN, HM_OUT, DMA, EPI, KW3, CAT>;
+  using SM = GatherSmem<T, BM, BN, DMA ? 2 : 1, KW3>;
+  constexpr int smem = SM::kBytes + (KG - 1) * 2 * SM::kStage;
+  auto kern = gather_gemm_kernel<T, BM, BN, SMALL_C, WGM, WGN, HM_OUT, DMA, EPI, KW3, CAT, KG>;
   static bool attr_set = false;   // raise the dynamic-LDS cap once per instantiation
   if (!attr_set) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem); attr_set = true; }
-  hipLaunchKernelGGL(kern, dim3(a.ntiles), dim3(64 * WGM * WGN), smem, st, a);
+  hipLaunchKernelGGL(kern, dim3(a.ntiles), dim3(64 * WGM * WGN * KG), smem, st, a);
 }
 
-template <typename T, int BM, int BN, bool SMALL_C, int WGM = 2, int WGN = 2, bool HM_OUT = false, bool DMA = false, bool KW3 = false, bool CAT = false>
+template <typename T, int BM, int BN, bool SMALL_C, int WGM = 2, int WGN = 2, bool HM_OUT = false, bool DMA = false, bool KW3 = false, bool CAT = false, int KG = 1>
 static void launch_gather(GatherArgs& a, hipStream_t st) {
   a.ntn = cdiv(a.Nout, BN);
   int mx = 0;
@@ -1221,7 +1279,7 @@ static void launch_gather(GatherArgs& a, hipStream_t st) {
     if (even && (size_t)a.nphase * mx * a.Nout * 2 * sizeof(float) <= a.stat_bytes) a.stat_slices = a.nphase * mx;
     else a.bnb_partial = nullptr;
   }
-  constexpr bool EXTRAS = !HM_OUT && BM <= 128 && !CAT;     // the BatchNorm-backward epilogue exists for the regular tiles only
+  constexpr bool EXTRAS = !HM_OUT && BM <= 128 && !CAT && KG == 1;     // the BatchNorm-backward epilogue exists for the regular tiles only
   constexpr bool STATS = !HM_OUT && (BM <= 128 || (BM == 256 && BN == 128));   // statistics: also the 256x128 macro tile
   if (!EXTRAS && a.bnb_partial) a.bnb_partial = nullptr;
   static const bool stats256 = !(getenv("MI355_STATS_256") && atoi(getenv("MI355_STATS_256")) == 0);      // A/B switch
@@ -1231,9 +1289,9 @@ static void launch_gather(GatherArgs& a, hipStream_t st) {
     if (a.bnb_partial) { launch_gather_epi<T, BM, BN, SMALL_C, WGM, WGN, HM_OUT, DMA, 2>(a, st); return; }     // (EPI 2 has no KW3 build)
   }
   if constexpr (STATS) {
-    if (a.stat_partial) { launch_gather_epi<T, BM, BN, SMALL_C, WGM, WGN, HM_OUT, DMA, 1, KW3, CAT>(a, st); return; }
+    if (a.stat_partial) { launch_gather_epi<T, BM, BN, SMALL_C, WGM, WGN, HM_OUT, DMA, 1, KW3, CAT, KG>(a, st); return; }
   }
-  launch_gather_epi<T, BM, BN, SMALL_C, WGM, WGN, HM_OUT, DMA, 0, KW3, CAT>(a, st);
+  launch_gather_epi<T, BM, BN, SMALL_C, WGM, WGN, HM_OUT, DMA, 0, KW3, CAT, KG>(a, st);
 }
 
 template <typename T>
@@ -1297,6 +1355,9 @@ static int dispatch_gather(GatherArgs& a, hipStream_t st) {
     const long t128 = cdiv(Mtot, 128L) * cdiv(a.Nout, 128);
     // 3x3 / unit stride / same-size maps of a power-of-two width <= 128: the A-tile-sharing variant (see KW3 above)
     static const int kw3_on = getenv("MI355_KW3") ? atoi(getenv("MI355_KW3")) : 1;
+    static const int splitk_on = getenv("MI355_SPLITK") ? atoi(getenv("MI355_SPLITK")) : 1;                 // A/B switch
+    static const long splitk_min = getenv("MI355_SPLITK_MIN") ? atol(getenv("MI355_SPLITK_MIN")) : 128;
+    static const long splitk_max = getenv("MI355_SPLITK_MAX") ? atol(getenv("MI355_SPLITK_MAX")) : 320;
     bool kw3 = kw3_on && sizeof(T) == 2 && a.nphase == 1 && a.ph[0].ntaps == 9 && a.in_sx == 1 && a.in_sy == 1 && a.out_sx == 1 &&
                a.out_sy == 1 && a.ph[0].OWp == a.Wi && a.ph[0].OHp == a.Hi && a.Wo == a.Wi && a.Ho == a.Hi && a.Wi >= 8 &&
                a.Wi <= 128 && ilog2_exact(a.Wi) >= 0 && a.Nout > 64 && a.Ci % 64 == 0 && !a.bnb_partial;
@@ -1318,6 +1379,8 @@ static int dispatch_gather(GatherArgs& a, hipStream_t st) {
     else if (kw3 && (t128 >= 2048 || kw3_on == 2)) { if constexpr (sizeof(T) == 2) launch_gather<T, 128, 128, false, 2, 2, false, false, true>(a, st); }
     // (also the K-heavy mid-size layers, 256 .. 511 tiles with K >= 2048: 3x3 256->256 @16x16 36.2 -> 32.7 us; a 3-stage ring with
     //  two tiles in flight and counted vmcnt measured 33.5 us there: the per-CU fill rate, not latency, bounds these layers)
+    // one 128 x 128 tile per CU or fewer and a long K: two K groups per workgroup (KG above) -- 3x3 256 -> 256 @16x16 and kin
+    else if (splitk_on && dma_mode == 1 && t128 >= splitk_min && t128 <= splitk_max && kavg >= 256 && !a.bnb_partial) launch_gather<T, 128, 128, false, 2, 2, false, true, false, false, 2>(a, st);
     else if ((dma_mode == 2 && a.Nout > 64) || (dma_mode == 1 && ((t128 >= 512 && kavg >= 128) || (t128 >= 256 && kavg >= 256)))) launch_gather<T, 128, 128, false, 2, 2, false, true>(a, st);
     // short-K 1x1 convs at large M are all prologue / epilogue and HBM-bound: more, smaller blocks in flight win
     // (64->256 @64x64: 54.5 -> 47.0 us, 256->256: 79.6 -> 68.9 us)
@@ -1754,7 +1817,7 @@ static long kw_group_plan(const mi355_wgrad_item* items, const int* idx, int n, 
     const mi355_conv_desc* d = &items[idx[k]].d; WgradPlan w = plan_wgrad(d);
     W += (double)w.nto * 3 * w.nti * (((long)d->N * d->Ho * d->Wo + 63) / 64);
   }
-  static const int group_blocks = getenv("MI355_WG_KW_GROUP_BLOCKS") ? atoi(getenv("MI355_WG_KW_GROUP_BLOCKS")) : 768;
+  static const int group_blocks = getenv("MI355_WG_KW_GROUP_BLOCKS") ? atoi(getenv("MI355_WG_KW_GROUP_BLOCKS")) : 512;      // (512 / 768 / 1024: 32.47 / 32.55 / 32.64 ms per iteration, same box)
   long per = (long)(W / group_blocks) + 1; if (per < 16) per = 16;
   long blocks = 0; size_t off = 0;
   for (int k = 0; k < n; ++k) {

@@ -126,7 +126,8 @@ def test_conv_residual_epilogue(gpu, dt):
 
 
 @pytest.mark.parametrize('dt', ['f32', 'bf16'])
-@pytest.mark.parametrize('case', [(2, 64, 16, 16, 64, 1, 1, 0), (3, 256, 8, 8, 64, 1, 1, 0), (32, 64, 64, 64, 256, 3, 1, 1), (2, 64, 16, 16, 128, 3, 2, 1)])
+@pytest.mark.parametrize('case', [(2, 64, 16, 16, 64, 1, 1, 0), (3, 256, 8, 8, 64, 1, 1, 0), (32, 64, 64, 64, 256, 3, 1, 1), (2, 64, 16, 16, 128, 3, 2, 1),
+                                  (64, 256, 16, 16, 256, 3, 1, 1)])      # the last one: two K groups per workgroup
 def test_conv_dgrad_accumulates_onto_a_bit_masked_gradient(gpu, dt, case):
     """dx <- dgrad + (bit ? dx : 0): the fork of a residual block whose identity-branch gradient still lacks the block's
     ReLU mask (mi355_conv_dgrad_masked_acc), and the stand-alone masking kernel; both against plain tensor arithmetic, and
@@ -273,6 +274,8 @@ STAT_CASES = [
     ('conv', 20, 64, 64, 64, 128, 1, 1, 0),    # 81920 rows: >= 640 slices -> the block-per-channel finalize kernel
     ('deconv', 2, 256, 16, 16, 64, 4, 2, 1),   # four output phases in one launch
     ('conv', 64, 64, 64, 64, 256, 3, 1, 1),    # 4096 output tiles: the 256x128 macro tile of the shared-A-tile kernel with the statistics epilogue
+    ('conv', 64, 256, 16, 16, 256, 3, 1, 1),   # 256 output tiles, K = 2304: two K groups per workgroup (intra-workgroup split-K), statistics by all 8 waves
+    ('deconv', 64, 256, 8, 8, 256, 4, 2, 1),   # the same through the four phases of a transposed conv (2048 -> 256 @8 -> 16 is the model's; here 256 -> 256)
 ]
 
 
