@@ -212,8 +212,22 @@ def main():
         use_graph = step.choose_launch_mode(batch, after=tick) == 'graph'
         log('multi-rank launch mode: host/GPU time ratio %.2f -> %s' % (step.host_gpu_ratio, 'graph replay' if use_graph else 'eager + overlapped all-reduce'))
     if use_graph:
-        step.capture(batch, warmup=0)
-        log('graphs captured')
+        ok = 1
+        try:
+            step.capture(batch, warmup=0)
+            if world > 1:                  # one trial replay before the timed region: a capture problem must not cost the run
+                step.run(batch); tick(); torch.cuda.synchronize()
+        except Exception as e:             # noqa: BLE001 -- any failure of the captured path falls back to eager launches
+            ok = 0
+            log('graph capture / trial replay failed (%s: %s): falling back to eager launches' % (type(e).__name__, e))
+        if world > 1:
+            f = torch.tensor([ok], device=dev, dtype=torch.int32)
+            dist.all_reduce(f, op=dist.ReduceOp.MIN)
+            ok = int(f)
+        if ok:
+            log('graphs captured' + (' (gradient exchange captured with them)' if getattr(step, 'exchange_captured', False) else ''))
+        else:
+            step.graphs, step.exchange_captured, use_graph = None, False, False
     for _ in range(max(0, args.warmup - n_eager)):
         step.run(batch); tick()
 
@@ -329,6 +343,9 @@ def main():
                                    'random init, synthetic batches' % (args.arch, S, S, B, B),
                        'arch': args.arch, 'image_size': S, 'per_gpu_batch': B, 'global_batch': B * world,
                        'parallelism': 'dp%d' % world, 'hip_graphs': use_graph,
+                       'gradient_exchange': ('none (one rank)' if world == 1 else 'RCCL all-reduce captured into the graphs, overlapped with the backward'
+                                             if getattr(step, 'exchange_captured', False) else 'between the graphs (blocking)' if use_graph
+                                             else 'eager, overlapped with the backward'),
                        **({'fp8_gemms': 'forward + input gradient of the 3x3 convs'
                            + (', transposed convs' if os.environ.get('MI355_FP8_DECONV', '0') == '1' else '')
                            + (', weight gradients' if os.environ.get('MI355_FP8_WGRAD', '0') == '1' else '')}

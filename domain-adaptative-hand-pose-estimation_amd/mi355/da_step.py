@@ -170,10 +170,19 @@ class DAStep:
         if self._reducer is not None:
             self._reducer.stage_done(stage)
 
+    def _overlap_capturable(self):
+        """Can the overlapped exchange be CAPTURED into the HIP graphs?  RCCL collectives are stream work and capture like kernels
+        (probed on this stack: scratch/rccl_graph_probe.py -- an async all-reduce on RCCL's stream inside torch.cuda.graph, replayed);
+        gloo collectives are host work and cannot.  MI355_DDP_GRAPH_OVERLAP=0 keeps the blocking exchange between the graphs."""
+        return (self.overlap and _distributed() and dist.get_backend() == 'nccl' and
+                os.environ.get('MI355_DDP_GRAPH_OVERLAP', '1') == '1')
+
     def _begin_reduce(self, keys):
-        """Arm the overlapped reducer for the backward about to run (eager, more than one rank)."""
+        """Arm the overlapped reducer for the backward about to run: more than one rank, launched eagerly -- or being captured with
+        a backend whose collectives capture (the all-reduces then sit in the graph on RCCL's stream, beside the rest of the backward)."""
+        capturing = torch.cuda.is_current_stream_capturing()
         self._reducer = _OverlapReducer(self, keys) if (self.overlap and _distributed() and
-                                                         not torch.cuda.is_current_stream_capturing()) else None
+                                                         (not capturing or self._overlap_capturable())) else None
         if self._reducer is not None:
             # collectives will run beside this backward: the one-launch BatchNorm backward needs every CU for its resident
             # blocks (mi355_bn_set_resident), so this pass takes the three-launch form
@@ -337,8 +346,23 @@ class DAStep:
         from uda.model.regda_4 import _CENTRES
         _CENTRES.clear()
         pool = torch.cuda.graph_pool_handle()
-        segs = [lambda: self._fwdbwd_A(self.static), self._update_A, lambda: self._fwdbwd_B(self.static),
-                self._update_B, lambda: (self._fwdbwd_C(self.static)), lambda: (self._update_C(), self._accuracy(self.static))]
+        KA, KB, KC = ('f', 'h', 'h_adv', 'h_adv2', 'h_adv3'), ('h_adv', 'h_adv2', 'h_adv3'), ('f',)
+        # With RCCL the gradient exchange is captured too: steps A and C with the overlapped reducer (its asynchronous all-reduces
+        # become a parallel branch of the backward's graph, started where the gradient hooks fire), step B's small exchange behind
+        # its backward.  Replay then issues no collective from the host.  Otherwise (one rank, gloo) the exchange stays between graphs.
+        self.exchange_captured = self._overlap_capturable()
+        if self.exchange_captured:
+            def seg_a():
+                self._begin_reduce(KA); self._fwdbwd_A(self.static); self._end_reduce(KA)
+
+            def seg_b():
+                self._fwdbwd_B(self.static); _allreduce_mean(self._grads(KB))
+
+            def seg_c():
+                self._begin_reduce(KC); self._fwdbwd_C(self.static); self._end_reduce(KC)
+        else:
+            seg_a, seg_b, seg_c = (lambda: self._fwdbwd_A(self.static)), (lambda: self._fwdbwd_B(self.static)), (lambda: self._fwdbwd_C(self.static))
+        segs = [seg_a, self._update_A, seg_b, self._update_B, seg_c, lambda: (self._update_C(), self._accuracy(self.static))]
         graphs = []
         for fn in segs:
             g = torch.cuda.CUDAGraph()
@@ -349,8 +373,9 @@ class DAStep:
         return self
 
     def choose_launch_mode(self, batch, after=None, threshold=0.95):
-        """Multi-rank runs: eager launches keep the gradient exchange overlapped with the backward, but only pay off while the
-        host can feed the GPU.  Times one eager iteration on the host (enqueue) and on the GPU (enqueue + drain); if enqueueing
+        """Multi-rank runs.  With RCCL the overlapped gradient exchange is captured into the HIP graphs, so graph replay is chosen
+        outright.  With a backend whose collectives cannot be captured (gloo rehearsals): eager launches keep the exchange
+        overlapped with the backward, but only pay off while the host can feed the GPU.  Times one eager iteration on the host (enqueue) and on the GPU (enqueue + drain); if enqueueing
         takes (nearly) as long as running it on ANY rank, every rank should replay graphs instead (collectives between the
         graphs).  Runs one real iteration (`after()` is called behind it: scheduler ticks) and returns 'graph' or 'eager' --
         the same answer on every rank (MAX over ranks).  MI355_DDP_GRAPH=1 / 0 forces the answer."""
@@ -370,6 +395,8 @@ class DAStep:
         self.host_gpu_ratio = float(r)
         if forced in ('0', '1'):
             return 'graph' if forced == '1' else 'eager'
+        if self._overlap_capturable():
+            return 'graph'          # RCCL: the overlapped exchange is captured into the graphs -- replay loses nothing and cannot go host-bound
         return 'graph' if self.host_gpu_ratio > threshold else 'eager'
 
     def _host_tick(self):
@@ -387,15 +414,19 @@ class DAStep:
                     self.static[k].copy_(v, non_blocking=True)
         self._host_tick()
         g = self.graphs
-        g[0].replay()
-        _allreduce_mean(self._grads(('f', 'h', 'h_adv', 'h_adv2', 'h_adv3')))
-        g[1].replay()
-        g[2].replay()
-        _allreduce_mean(self._grads(('h_adv', 'h_adv2', 'h_adv3')))
-        g[3].replay()
-        g[4].replay()
-        _allreduce_mean(self._grads(('f',)))
-        g[5].replay()
+        if getattr(self, 'exchange_captured', False):      # the collectives are nodes of the graphs
+            for gr in g:
+                gr.replay()
+        else:
+            g[0].replay()
+            _allreduce_mean(self._grads(('f', 'h', 'h_adv', 'h_adv2', 'h_adv3')))
+            g[1].replay()
+            g[2].replay()
+            _allreduce_mean(self._grads(('h_adv', 'h_adv2', 'h_adv3')))
+            g[3].replay()
+            g[4].replay()
+            _allreduce_mean(self._grads(('f',)))
+            g[5].replay()
         self.model.step()
         return self.out
 

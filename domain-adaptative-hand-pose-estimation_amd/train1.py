@@ -310,7 +310,8 @@ def train(train_source_iter, train_target_iter, step, scheds, epoch, args):
             if WORLD > 1:
                 mode = step.choose_launch_mode(batch, after=lambda: [s.step() for s in scheds.values()])
                 print('multi-rank launch mode: host / GPU time of an eager iteration %.2f -> %s'
-                      % (step.host_gpu_ratio, 'HIP-graph replay, collectives between the graphs' if mode == 'graph'
+                      % (step.host_gpu_ratio, ('HIP-graph replay, overlapped RCCL gradient exchange captured with the graphs' if step._overlap_capturable()
+                                                 else 'HIP-graph replay, collectives between the graphs') if mode == 'graph'
                          else 'eager launches, gradient exchange overlapped with the backward'))
                 step.eager_iters += 1
                 end = time.time()

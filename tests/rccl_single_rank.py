@@ -41,7 +41,11 @@ def main():
         step.run(batch)
         tick()
     mode = step.choose_launch_mode(batch, after=tick)      # includes the MAX all-reduce of the decision
-    step.capture(batch, warmup=0)           # graph replay: blocking all-reduces between the six graphs
+    n_eager = len(launched)
+    # graph replay: with RCCL the overlapped exchange is captured into the graphs (MI355_DDP_GRAPH_OVERLAP=0: blocking all-reduces
+    # between the six graphs instead)
+    step.capture(batch, warmup=0)
+    n_captured = len(launched) - n_eager
     for _ in range(2):
         step.run(batch)
         tick()
@@ -51,7 +55,8 @@ def main():
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
-    print(json.dumps({'checksums': cs, 'collective_launches': len(launched), 'mode': mode, 'backend': backend}))
+    print(json.dumps({'checksums': cs, 'collective_launches': len(launched), 'captured_launches': n_captured, 'mode': mode, 'backend': backend,
+                      'exchange_captured': bool(getattr(step, 'exchange_captured', False))}))
 
 
 if __name__ == '__main__':

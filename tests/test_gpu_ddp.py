@@ -107,8 +107,9 @@ def test_train_cli_with_two_ranks(gpu, tmp_path):
 def test_rccl_single_rank_smoke(gpu):
     """RCCL itself (backend 'nccl'), which the two-rank tests above cannot use on a one-GPU box: a ONE-rank group with every
     collective of the multi-rank path forced on (MI355_DDP_FORCE_COLLECTIVES) -- init, parameter broadcast of the conv-form
-    views, asynchronous AVG all-reduces of flat fp32 gradient ranges started from the backward's hooks, the blocking exchange
-    between replayed graphs, the MAX all-reduce of the launch-mode decision, barrier (tests/rccl_single_rank.py, one process per
+    views, asynchronous AVG all-reduces of flat fp32 gradient ranges started from the backward's hooks, the same exchange CAPTURED
+    into the replayed graphs (and, switched off, the blocking exchange between the graphs), the MAX all-reduce of the launch-mode
+    decision, barrier (tests/rccl_single_rank.py, one process per
     run).  A mean over one rank is the identity: the parameters after six iterations must equal those of the same run without
     a process group, bit for bit."""
     import json
@@ -116,13 +117,18 @@ def test_rccl_single_rank_smoke(gpu):
     import sys
     here = os.path.dirname(os.path.abspath(__file__))
     out = []
-    for use_dist in ('1', '0'):
+    for use_dist, graph_overlap in (('1', '1'), ('1', '0'), ('0', '1')):
         env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(_free_port()), MI355_DDP_FORCE_COLLECTIVES=use_dist,
-                   MI355_OVERLAP_ALLREDUCE='1', MI355_BN_RESIDENT='0')       # (same BatchNorm-backward kernels in both runs)
+                   MI355_OVERLAP_ALLREDUCE='1', MI355_BN_RESIDENT='0',        # (same BatchNorm-backward kernels in all runs)
+                   MI355_DDP_GRAPH_OVERLAP=graph_overlap)
         r = subprocess.run([sys.executable, os.path.join(here, 'rccl_single_rank.py'), use_dist], env=env, capture_output=True, text=True, timeout=240)
         assert r.returncode == 0, r.stderr[-3000:]
         out.append(json.loads(r.stdout.strip().splitlines()[-1]))
-    d, p = out
+    d, b, p = out
     assert d['collective_launches'] > 0 and p['collective_launches'] == 0      # the overlapped reducer really issued RCCL collectives
     assert d['mode'] in ('graph', 'eager') and d['backend'] == 'nccl'
-    assert d['checksums'] == p['checksums']
+    # graph replay: the overlapped exchange was captured into the graphs (its all-reduces issued during capture, none from the host
+    # at replay) -- or, switched off, stayed between the graphs; either way the same bits as without a process group
+    assert d['exchange_captured'] and d['captured_launches'] > 0
+    assert not b['exchange_captured'] and b['captured_launches'] == 0
+    assert d['checksums'] == p['checksums'] and b['checksums'] == p['checksums']
