@@ -47,6 +47,7 @@ struct GatherArgs {
   // c2 <= one K tile.  `heatmap_conv(y) + feature_conv(f)` of the multiscale-fusion heads as one GEMM (regda_7.py:4573-4581).
   const void* A2; const void* B2; const float* bias2;
   int c2; unsigned a2_bytes, b2_bytes;
+  int pg_nadd;                 // (pgemm.hip, ADD build) slots of the addend ring
 };
 
 // 16-byte chunk with the elements whose mask bit is clear set to zero (bit e = element e; bf16: two elements per word)

@@ -63,11 +63,28 @@ template <int N> __device__ __forceinline__ void wait_vm() {
   static_assert(N >= 0, "vmcnt immediate");
   asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N > 63 ? 63 : N) : "memory");
 }
+// s_waitcnt vmcnt(a) for a wave-uniform run-time allowance: the immediate is the largest even number <= min(a, 62)
+__device__ __forceinline__ void wait_vm_dyn(int a) {
+  switch (a >> 1) {
+    case 0: wait_vm<0>(); break;   case 1: wait_vm<2>(); break;   case 2: wait_vm<4>(); break;   case 3: wait_vm<6>(); break;
+    case 4: wait_vm<8>(); break;   case 5: wait_vm<10>(); break;  case 6: wait_vm<12>(); break;  case 7: wait_vm<14>(); break;
+    case 8: wait_vm<16>(); break;  case 9: wait_vm<18>(); break;  case 10: wait_vm<20>(); break; case 11: wait_vm<22>(); break;
+    case 12: wait_vm<24>(); break; case 13: wait_vm<26>(); break; case 14: wait_vm<28>(); break; case 15: wait_vm<30>(); break;
+    case 16: wait_vm<32>(); break; case 17: wait_vm<34>(); break; case 18: wait_vm<36>(); break; case 19: wait_vm<38>(); break;
+    case 20: wait_vm<40>(); break; case 21: wait_vm<42>(); break; case 22: wait_vm<44>(); break; case 23: wait_vm<46>(); break;
+    case 24: wait_vm<48>(); break; case 25: wait_vm<50>(); break; case 26: wait_vm<52>(); break; case 27: wait_vm<54>(); break;
+    case 28: wait_vm<56>(); break; case 29: wait_vm<58>(); break; case 30: wait_vm<60>(); break; default: wait_vm<62>(); break;
+  }
+}
 
-// ADD: the build whose epilogue reads global memory (residual / the gradient accumulated onto / its bit mask).  A build of its own:
-// a wave consumes its vector-memory results in issue order, so an epilogue load can only be used once every ring stage issued
-// before it has landed, and hipcc guards the load's destination registers with vmcnt(0) in the K loop even when the branch is not
-// taken -- the plain builds must not contain such loads at all.
+// ADD: the build whose epilogue adds a tensor read from global memory (residual / the gradient accumulated onto, with its bit mask).
+// A wave consumes its vector-memory results in issue order, so an epilogue load could only be used once every ring stage issued
+// before it had landed (one memory latency per tile), and hipcc guards such a load's destination registers with vmcnt(0) in the
+// K loop even when the branch is not taken.  So the addends never travel through registers: a tile's addend tile (and mask bytes)
+// is fetched by LDS-DMA into a slot of an ADDEND RING, issued IN FRONT OF the activation pieces of the tile's first K step -- older
+// than they are, hence landed whenever that stage's counted wait returns -- NS - 1 K steps before the tile's first MFMA; the epilogue
+// reads it from LDS.  Slots: floor((NS - 1) / nk) + 2 (GatherArgs.pg_nadd), so a slot is rewritten only after the tile that used
+// it has left its epilogue behind a K-step barrier.  A build of its own: the plain builds contain no such traffic at all.
 template <int BM, int BN, int NS, int EPI, bool ADD>
 __global__ __launch_bounds__(256) void pgemm_kernel(const GatherArgs p) {
   constexpr int CH = 8, NTHR = 256;
@@ -96,12 +113,25 @@ __global__ __launch_bounds__(256) void pgemm_kernel(const GatherArgs p) {
   const int total = my_tiles * nk;
   if (total == 0) return;
   const unsigned ring_base = smem_base + (unsigned)(nk * BN * 128), out_base = ring_base + (unsigned)(NS * SM::kStage);
+  constexpr int kMask = BM * BN / 8;                         // mask bytes of a tile (one bit per element)
+  const int nadd = ADD ? p.pg_nadd : 0;
+  const unsigned add_base = out_base + (unsigned)SM::kOut, mask_base = add_base + (unsigned)(nadd * SM::kOut);
+  const int add_off = nk * BN * 128 + NS * SM::kStage + SM::kOut;      // (byte offsets of the same two regions from smem)
+  const int mask_off = add_off + nadd * SM::kOut;
 
   const __amdgpu_buffer_rsrc_t rsA = make_rsrc(p.A, p.a_bytes), rsB = make_rsrc(p.B, p.b_bytes);
   (void)rsA; (void)rsB;                                      // (only used in the device pass)
 
   // ---- issue side: tile / K step of the next LDS-DMA stage to launch
-  int is_tile = 0, is_kt = 0, is_gs = 0, is_slot = 0;
+  int is_tile = 0, is_kt = 0, is_gs = 0, is_slot = 0, is_add = 0;
+  constexpr int RPI = 1024 / (BN * 2), PADD = BM / (4 * RPI);    // rows of an addend tile per 1-KiB piece; pieces per wave
+  constexpr int NMD = kMask / 4;                             // mask dwords of a tile (waves 0 .. NMD / 64 - 1 fetch 64 each)
+  const bf16_t* __restrict__ ADDSRC = !ADD ? nullptr : (p.residual ? reinterpret_cast<const bf16_t*>(p.residual)
+                                                                  : (p.accumulate ? reinterpret_cast<const bf16_t*>(p.D) : nullptr));
+  const bool use_mask = ADD && p.accumulate && !p.residual && p.acc_mask != nullptr;
+  const __amdgpu_buffer_rsrc_t rsADD = make_rsrc(ADD ? (const void*)ADDSRC : p.A, ADD && ADDSRC ? (unsigned)((long)M * p.ldd * 2) : 0u);
+  const __amdgpu_buffer_rsrc_t rsMSK = make_rsrc(use_mask ? (const void*)p.acc_mask : p.A, use_mask ? (unsigned)((long)M * p.ldd / 8) : 0u);
+  (void)rsADD; (void)rsMSK;
   int voffA[PA];
   auto set_issue_tile = [&](int i) {
     const int tm = gm + i * Gm;
@@ -113,6 +143,25 @@ __global__ __launch_bounds__(256) void pgemm_kernel(const GatherArgs p) {
     (void)soff; (void)wave_u;
 #if defined(__HIP_DEVICE_COMPILE__)
     typedef __attribute__((address_space(3))) void* ldsp;
+    if constexpr (ADD) {
+      if (is_kt == 0 && ADDSRC) {        // (block-uniform) this tile's addend tile and mask bytes first: older than the stage's pieces
+        const int tm = gm + is_tile * Gm;
+        char* sd = smem + add_off + is_add * SM::kOut;
+#pragma unroll
+        for (int j = 0; j < PADD; ++j) {
+          const int q = j * 4 + wave_u;                      // piece q = rows q * RPI .. of the tile, row-major image
+          const int m = tm * BM + q * RPI + lane / CPR, n = tn * BN + (lane % CPR) * CH;
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsADD, (ldsp)(sd + q * 1024), 16, (m < M && n < p.Nout) ? (m * p.ldd + n) * 2 : OOB_OFF, 0, 0, 0);
+        }
+        if (use_mask && wave_u * 64 < NMD) {
+          const int d = wave_u * 64 + lane;                  // dword d of the tile's [BM][BN / 8] mask bytes
+          const int m = tm * BM + d / (BN / 32), nb = tn * (BN / 8) + (d % (BN / 32)) * 4;
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsMSK, (ldsp)(smem + mask_off + is_add * kMask + wave_u * 256), 4,
+                                                   (m < M && nb * 8 < p.Nout) ? m * (p.ldd / 8) + nb : OOB_OFF, 0, 0, 0);
+        }
+        if (++is_add == nadd) is_add = 0;
+      }
+    }
     char* sa = smem + nk * BN * 128 + is_slot * SM::kStage + wave_u * 1024;
 #pragma unroll
     for (int j = 0; j < PA; ++j) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (ldsp)(sa + j * 4096), 16, voffA[j], soff, 0, 0);
@@ -295,24 +344,26 @@ __global__ __launch_bounds__(256) void pgemm_kernel(const GatherArgs p) {
   float st_n = 0.f, st_ref[CH], st_s[CH], st_q[CH];
 #pragma unroll
   for (int e = 0; e < CH; ++e) { st_ref[e] = 0.f; st_s[e] = 0.f; st_q[e] = 0.f; }
-  const bf16_t* __restrict__ ADDP = !ADD ? nullptr : (R ? R : (p.accumulate ? (const bf16_t*)D : nullptr));     // the addend read up front (residual or the running dx)
+  int cons_add = 0;                                          // slot of the addend ring the next epilogue reads
   auto epilogue = [&](unsigned outs, int tm) {
     const int m0 = tm * BM, n0 = tn * BN;
     const int n = n0 + ec * CH;
     const int rows_left = M - (m0 + er0);                    // chunk k is inside the matrix iff k * RSTEP < rows_left
     const size_t g0 = (size_t)(m0 + er0) * p.ldd + n;
-    // addends (residual / the gradient accumulated onto) and mask bytes of all this thread's chunks: in flight during the staging
-    uint4 qadd[ADD ? IT : 1]; unsigned mk[ADD ? IT : 1];
-    if constexpr (ADD) if (ADDP) {
+    // addends (residual / the gradient accumulated onto) and mask bytes of this thread's chunks, from the tile's slot of the
+    // addend ring (landed since the counted wait of the tile's first K step; published by that step's barrier)
+    u32x4_t qadd[ADD ? IT : 1]; unsigned mk[ADD ? IT : 1];
+    if constexpr (ADD) if (ADDSRC) {
+      const unsigned ab = add_base + (unsigned)(cons_add * SM::kOut) + (unsigned)(er0 * BN * 2 + ec * 16);
+      const unsigned mb = mask_base + (unsigned)(cons_add * kMask) + (unsigned)(er0 * (BN / 8) + ec);
 #pragma unroll
       for (int k = 0; k < IT; ++k) {
-        qadd[k] = make_uint4(0, 0, 0, 0); mk[k] = 0xffu;
-        if (k * RSTEP < rows_left && n < p.Nout) {
-          const size_t g = g0 + (size_t)k * RSTEP * p.ldd;
-          qadd[k] = *reinterpret_cast<const uint4*>(ADDP + g);
-          if (p.acc_mask && !R) mk[k] = p.acc_mask[g / CH];
-        }
+        qadd[k] = lds_read16u(ab + (unsigned)(k * RSTEP * BN * 2));
+        mk[k] = 0xffu;
+        if (use_mask) { unsigned v; asm volatile("ds_read_u8 %0, %1" : "=v"(v) : "v"(mb + (unsigned)(k * RSTEP * (BN / 8)))); mk[k] = v; }
       }
+      LDS_WAIT_ALL();
+      if (++cons_add == nadd) cons_add = 0;
     }
     asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");       // the last MFMAs' results before hipcc's reads of them (asm is opaque to its hazard pass)
     // (the staging region is this kernel's own: every wave left the previous tile's epilogue reads behind at one of the K-step
@@ -368,13 +419,10 @@ __global__ __launch_bounds__(256) void pgemm_kernel(const GatherArgs p) {
         if (plain) { *reinterpret_cast<uint4*>(D + g) = qk; continue; }
       }
       if constexpr (ADD) {
-        if (R) { float w[CH]; Chunk<bf16_t>::unpack(qadd[k], w);
-#pragma unroll
-          for (int e = 0; e < CH; ++e) v[e] += w[e]; }
-        if (p.accumulate) {
-          uint4 qa = R ? *reinterpret_cast<const uint4*>(D + g) : qadd[k];     // (both at once: not used by this model)
+        if (ADDSRC) {      // residual, or the gradient accumulated onto (not both: the host sends such a launch to the gather kernel)
+          uint4 qa = make_uint4(qadd[k][0], qadd[k][1], qadd[k][2], qadd[k][3]);
           // the bit mask is applied on the packed words (see igemm.hip / DESIGN.md section 7)
-          if (p.acc_mask) qa = keep_masked<bf16_t>(qa, R ? (unsigned)p.acc_mask[g / CH] : mk[k]);
+          if (use_mask) qa = keep_masked<bf16_t>(qa, mk[k]);
           float w[CH]; Chunk<bf16_t>::unpack(qa, w);
 #pragma unroll
           for (int e = 0; e < CH; ++e) v[e] += w[e]; }
@@ -406,15 +454,24 @@ __global__ __launch_bounds__(256) void pgemm_kernel(const GatherArgs p) {
       // Counting the ring loads alone let a tile's stores eat the allowance: with one K step per tile the ring ran one deep.
       constexpr int W = (DIST - 1) * PA;
       const int c = __builtin_amdgcn_readfirstlane(__builtin_popcount(epi_hist & ((1u << DIST) - 1u)));       // full-tile epilogues within the last DIST steps
-      switch (c) {
-        case 0: wait_vm<W>(); break;
-        case 1: wait_vm<W + IT>(); break;
-        case 2: wait_vm<W + 2 * IT>(); break;
-        case 3: wait_vm<W + 3 * IT>(); break;
-        case 4: wait_vm<W + 4 * IT>(); break;
-        case 5: wait_vm<W + 5 * IT>(); break;
-        case 6: wait_vm<W + 6 * IT>(); break;
-        default: wait_vm<W + 7 * IT>(); break;
+      if constexpr (ADD) {
+        // ... and the addend pieces issued in front of every younger stage that starts a tile (stage gs + j starts one iff
+        // (kt + j) % nk == 0; all DIST - 1 younger stages exist on this branch).  The mask piece is not counted (not every wave has one).
+        int starts = 0, kk = kt;
+#pragma unroll
+        for (int j = 1; j < DIST; ++j) { if (++kk == nk) kk = 0; starts += (kk == 0) ? 1 : 0; }
+        wait_vm_dyn(__builtin_amdgcn_readfirstlane(W + c * IT + (ADDSRC ? starts * PADD : 0)));
+      } else {
+        switch (c) {
+          case 0: wait_vm<W>(); break;
+          case 1: wait_vm<W + IT>(); break;
+          case 2: wait_vm<W + 2 * IT>(); break;
+          case 3: wait_vm<W + 3 * IT>(); break;
+          case 4: wait_vm<W + 4 * IT>(); break;
+          case 5: wait_vm<W + 5 * IT>(); break;
+          case 6: wait_vm<W + 6 * IT>(); break;
+          default: wait_vm<W + 7 * IT>(); break;
+        }
       }
     } else {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -516,7 +573,9 @@ static void launch_pgemm_epi(GatherArgs& a, int ncu, int ntm, int smem, hipStrea
 template <int BM, int BN, int NS>
 static bool launch_pgemm(GatherArgs& a, int ncu, hipStream_t st) {
   const int nk = a.Ci >> 6;
-  const int smem = PgSmem<BM, BN, NS>::bytes(nk);
+  const bool add = a.residual || a.accumulate;
+  a.pg_nadd = add ? (NS - 1) / nk + 2 : 0;                    // addend-ring slots (kernel comment): tile + mask bytes each
+  const int smem = PgSmem<BM, BN, NS>::bytes(nk) + a.pg_nadd * (PgSmem<BM, BN, NS>::kOut + BM * BN / 8);
   if (smem > 160 * 1024) return false;
   const int ntm = cdiv(a.ph[0].M, BM);
   a.ntn = cdiv(a.Nout, BN);
@@ -560,10 +619,13 @@ bool pgemm_eligible(const GatherArgs& a, int elem_size) {
   const long Mrows = a.ph[0].M;
   if (Mrows * a.Ci * 2 >= (1L << 31) || Mrows * a.Nout * 2 >= (1L << 31)) return false;
   if (Mrows < 256 || !pg_bn(a)) return false;
+  if (a.residual && a.accumulate) return false;               // (one addend tensor per tile in the addend ring)
+  if (a.acc_mask && (a.Nout % 32 || !a.accumulate)) return false;      // mask bytes travel as dwords
   if (mode >= 2) return true;
-  // the epilogues that read global memory (residual, accumulate) stay on the gather kernel: a wave consumes vector-memory results
-  // in issue order, so using such a load waits for every ring stage in flight -- one memory latency per tile
-  if (a.residual || a.accumulate) return false;
+  // residual / accumulate epilogues (addend ring): one block per CU carries ring, addend slots and a heavier epilogue -- measured
+  // 87 -> 74 us on 64 -> 256 @64x64 + residual (eval), 44 -> 46 us on 128 -> 512 @32x32 + residual: worth it for one K step per tile only
+  static const int add_maxk = getenv("MI355_PG_ADD") ? atoi(getenv("MI355_PG_ADD")) * 64 : 64;      // A/B switch: largest K taken (0 = none)
+  if ((a.residual || a.accumulate) && a.Ci > add_maxk) return false;
   // Where it wins against the gather kernel (profiles/r04_pgemm_layers.txt: per layer, operands from HBM): the large maps
   // (>= 32 K rows), with a short K (<= 128: wide outputs stream at 5 TB/s) or a narrow output (K = 256 -> 64 / 128 columns).
   // K = 256 -> 256 columns needs two column tiles, i.e. the activations twice (no gain), K = 512 leaves room for 64-wide
@@ -587,9 +649,11 @@ int dispatch_pgemm(GatherArgs& a, hipStream_t st) {
   // ring depth: the deepest ring with which TWO blocks still share a CU (each hides the other's epilogue), else the deepest that fits
   int ring = ring_env;
   if (!ring) {
-    const int fixed = nk * bn * 128 + 64 * bn * 2;
-    for (int ns : {8, 6, 5, 4}) if (!ring && fixed + ns * 64 * 128 <= 80 * 1024) ring = ns;
-    for (int ns : {8, 6, 5, 4}) if (!ring && fixed + ns * 64 * 128 <= 160 * 1024) ring = ns;
+    const bool add = a.residual || a.accumulate;
+    auto bytes = [&](int ns) { return nk * bn * 128 + ns * 64 * 128 + 64 * bn * 2 + (add ? ((ns - 1) / nk + 2) * (64 * bn * 2 + 64 * bn / 8) : 0); };
+    if (!add) for (int ns : {8, 6, 5, 4}) if (!ring && bytes(ns) <= 80 * 1024) ring = ns;      // two blocks per CU
+    for (int ns : {8, 6, 5, 4}) if (!ring && bytes(ns) <= 160 * 1024) ring = ns;
+    if (!ring) ring = 4;
   }
   bool ok = false;
   if (bn == 128) {
