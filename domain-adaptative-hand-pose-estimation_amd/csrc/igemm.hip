@@ -1355,7 +1355,8 @@ static int dispatch_gather(GatherArgs& a, hipStream_t st) {
     const long t128 = cdiv(Mtot, 128L) * cdiv(a.Nout, 128);
     // 3x3 / unit stride / same-size maps of a power-of-two width <= 128: the A-tile-sharing variant (see KW3 above)
     static const int kw3_on = getenv("MI355_KW3") ? atoi(getenv("MI355_KW3")) : 1;
-    static const int splitk_on = getenv("MI355_SPLITK") ? atoi(getenv("MI355_SPLITK")) : 1;                 // A/B switch
+    static const int splitk_on = getenv("MI355_SPLITK") ? atoi(getenv("MI355_SPLITK")) : 2;                 // A/B switch (1: 128 x 128 tiles only)
+    const long t64 = cdiv(Mtot, 64L) * cdiv(a.Nout, 128);
     static const long splitk_min = getenv("MI355_SPLITK_MIN") ? atol(getenv("MI355_SPLITK_MIN")) : 128;
     static const long splitk_max = getenv("MI355_SPLITK_MAX") ? atol(getenv("MI355_SPLITK_MAX")) : 320;
     bool kw3 = kw3_on && sizeof(T) == 2 && a.nphase == 1 && a.ph[0].ntaps == 9 && a.in_sx == 1 && a.in_sy == 1 && a.out_sx == 1 &&
@@ -1380,6 +1381,8 @@ static int dispatch_gather(GatherArgs& a, hipStream_t st) {
     // (also the K-heavy mid-size layers, 256 .. 511 tiles with K >= 2048: 3x3 256->256 @16x16 36.2 -> 32.7 us; a 3-stage ring with
     //  two tiles in flight and counted vmcnt measured 33.5 us there: the per-CU fill rate, not latency, bounds these layers)
     // one 128 x 128 tile per CU or fewer and a long K: two K groups per workgroup (KG above) -- 3x3 256 -> 256 @16x16 and kin
+    // fewer 128 x 128 tiles than CUs (the 8x8 maps: 128 of them would leave half the chip idle): 64-row tiles, two K groups each
+    else if (splitk_on >= 2 && dma_mode == 1 && t128 < 256 && t64 >= splitk_min && t64 <= 384 && kavg >= 256 && !a.bnb_partial) launch_gather<T, 64, 128, false, 2, 2, false, true, false, false, 2>(a, st);
     else if (splitk_on && dma_mode == 1 && t128 >= splitk_min && t128 <= splitk_max && kavg >= 256 && !a.bnb_partial) launch_gather<T, 128, 128, false, 2, 2, false, true, false, false, 2>(a, st);
     else if ((dma_mode == 2 && a.Nout > 64) || (dma_mode == 1 && ((t128 >= 512 && kavg >= 128) || (t128 >= 256 && kavg >= 256)))) launch_gather<T, 128, 128, false, 2, 2, false, true>(a, st);
     // short-K 1x1 convs at large M are all prologue / epilogue and HBM-bound: more, smaller blocks in flight win

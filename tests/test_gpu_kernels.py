@@ -65,6 +65,7 @@ CONV_CASES = [
     # variants only the benchmark's sizes select, against torch at full size (round-2 verdict, item 8)
     (64, 256, 64, 64, 256, 3, 2, 1),  # wgrad_kw2 at stage size + 4-phase strided dgrad + LDS-DMA ring forward (3x3 s2 256->256 @64->32, B=64)
     (64, 256, 16, 16, 256, 3, 1, 1),  # 256 tiles, K = 2304: the LDS-DMA ring on the mid-size layers (3x3 256->256 @16x16, B=64)
+    (64, 512, 8, 8, 512, 3, 1, 1),    # 128 tiles of 128 x 128: 64-row tiles with two K groups per workgroup (3x3 512->512 @8x8, B=64)
 ]
 
 
