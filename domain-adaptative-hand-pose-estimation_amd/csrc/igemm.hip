@@ -1396,12 +1396,17 @@ static int dispatch_gather(GatherArgs& a, hipStream_t st) {
   return MI355_OK;
 }
 
-static int check_desc(const mi355_conv_desc* d) {
+// crop_ok: the entry point also takes a CROPPED output -- the top-left Ho x Wo outputs of a unit-stride conv (forward and weight
+// gradient only).  That is how the 7x7 / stride-2 stem runs as a 4x4 conv over the space-to-depth image (window rows -2 .. +1:
+// pad 2, the 129th output row / column never computed).
+static int check_desc(const mi355_conv_desc* d, bool crop_ok = false) {
   if (!d) MI_FAIL(MI355_EINVAL, "null conv desc");
   if (d->dtype != MI355_F32 && d->dtype != MI355_BF16 && d->dtype != MI355_FP8) MI_FAIL(MI355_EINVAL, "bad dtype %d", d->dtype);
   if (d->kh * d->kw > MAX_TAPS || d->kh < 1 || d->kw < 1) MI_FAIL(MI355_EINVAL, "unsupported kernel %dx%d", d->kh, d->kw);
   if (d->stride < 1 || d->stride > 2) MI_FAIL(MI355_EINVAL, "unsupported stride %d", d->stride);
-  if (d->Ho != (d->Hi + 2 * d->pad - d->kh) / d->stride + 1 || d->Wo != (d->Wi + 2 * d->pad - d->kw) / d->stride + 1)
+  const int fho = (d->Hi + 2 * d->pad - d->kh) / d->stride + 1, fwo = (d->Wi + 2 * d->pad - d->kw) / d->stride + 1;
+  const bool cropped = crop_ok && d->stride == 1 && d->kh > 1 && d->dtype != MI355_FP8 && d->Ho >= 1 && d->Wo >= 1 && d->Ho <= fho && d->Wo <= fwo;
+  if (!cropped && (d->Ho != fho || d->Wo != fwo))
     MI_FAIL(MI355_EINVAL, "conv desc: output size %dx%d inconsistent with input %dx%d k%d s%d p%d", d->Ho, d->Wo, d->Hi, d->Wi, d->kh, d->stride, d->pad);
   // the kernels form signed 32-bit BYTE offsets and 32-bit buffer-resource sizes: bound bytes, not elements
   const long esz = d->dtype == MI355_F32 ? 4 : 2;      // (fp8 operands, bf16 results: bound by the wider side)
@@ -1429,7 +1434,7 @@ struct CatExtra { const void* x2; const void* w2; const float* bias2; int c2; };
 static int conv_fwd_impl(const mi355_conv_desc* d, const void* x, const void* w, const float* bias, const void* residual, void* y,
                          float* partial, size_t partial_bytes, int* nslices, void* stream, const mi355_bn_bwd_src* bn = nullptr,
                          const Fp8Extra* f8 = nullptr, int relu = 0, const CatExtra* cat = nullptr) {
-  if (int e = check_desc(d)) return e;
+  if (int e = check_desc(d, true)) return e;
   if ((d->dtype == MI355_FP8) != (f8 != nullptr)) MI_FAIL(MI355_EINVAL, "fp8 descriptors go through the *_fp8 entry points (and only they)");
   if (relu && (bn || f8 || partial)) MI_FAIL(MI355_EINVAL, "conv_fwd: the fused ReLU is an inference epilogue (no statistics / BatchNorm-backward / fp8 variant)");
   GatherArgs a; memset(&a, 0, sizeof(a));
@@ -1695,7 +1700,7 @@ extern "C" size_t mi355_conv_wgrad_workspace(const mi355_conv_desc* d) {
 
 extern "C" int mi355_conv_wgrad(const mi355_conv_desc* d, const void* x, const void* dy, float* dw, int accumulate,
                                 void* ws, size_t ws_bytes, void* stream) {
-  if (int e = check_desc(d)) return e;
+  if (int e = check_desc(d, true)) return e;
   hipStream_t st = as_stream(stream);
   const int CH = d->dtype == MI355_BF16 ? 8 : 4;
   if (d->Ci % CH || d->Co % CH) MI_FAIL(MI355_EINVAL, "wgrad: channels must be multiples of %d", CH);

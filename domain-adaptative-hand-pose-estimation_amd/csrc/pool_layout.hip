@@ -136,3 +136,85 @@ extern "C" int mi355_nhwc_to_nchw(const void* x, float* y, int N, int C, int H, 
   MI_CHECK_LAUNCH("nhwc_to_nchw");
   return MI355_OK;
 }
+
+// ---------------------------------------------------------------- stem as a 4x4 conv over the space-to-depth image
+// A 7x7 / stride-2 / pad-3 conv over a 3-channel image equals a 4x4 / unit-stride conv over the image folded 2x2 into channels:
+// y[oy][ox] = sum over block rows by = oy-2 .. oy+1 (bx alike) and the 2x2 pixels (dy, dx) inside a block, with image row
+// 2*by + dy = 2*oy - 3 + kh, i.e. kh = 2*(by - oy + 2) + dy - 1 (the combination kh = -1 carries a zero weight).  K = 16 taps x 16
+// channels = 256 (four full K tiles) instead of 49 taps x 8 padded channels = 392 (seven, the last one nearly empty), and the folded
+// image is half the bytes of the channel-padded one.  Folded channel = (dy*2 + dx)*4 + c, c = 3 is zero.
+template <typename T>
+__global__ __launch_bounds__(256) void nchw_to_s2d_kernel(const float* __restrict__ x, T* __restrict__ y, int N, int H, int W) {
+  const int H2 = H >> 1, W2 = W >> 1;
+  const long total = (long)N * H2 * W2;
+  const size_t plane = (size_t)H * W;
+  for (long id = (long)blockIdx.x * 256 + threadIdx.x; id < total; id += (long)gridDim.x * 256) {
+    const int bx = (int)(id % W2); long r = id / W2; const int by = (int)(r % H2); const int n = (int)(r / H2);
+    float v[16];
+#pragma unroll
+    for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const float2 q = *reinterpret_cast<const float2*>(x + ((size_t)n * 3 + c) * plane + (size_t)(2 * by + dy) * W + 2 * bx);
+        v[(dy * 2 + 0) * 4 + c] = q.x; v[(dy * 2 + 1) * 4 + c] = q.y;
+      }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) v[q * 4 + 3] = 0.f;
+    T* o = y + (size_t)id * 16;
+    constexpr int CH = Chunk<T>::N;
+#pragma unroll
+    for (int k = 0; k < 16 / CH; ++k) {
+      float g[CH];
+#pragma unroll
+      for (int e = 0; e < CH; ++e) g[e] = v[k * CH + e];
+      Chunk<T>::store(o + k * CH, g);
+    }
+  }
+}
+
+extern "C" int mi355_nchw_to_s2d(const float* x, void* y, int N, int H, int W, int dtype, void* stream) {
+  if (!x || !y || N < 1 || H < 2 || W < 2 || (H & 1) || (W & 1)) MI_FAIL(MI355_EINVAL, "nchw_to_s2d: a 3-channel image with even extents (got %dx%d)", H, W);
+  if (dtype != MI355_BF16 && dtype != MI355_F32) MI_FAIL(MI355_EINVAL, "nchw_to_s2d: dtype %d", dtype);
+  long total = (long)N * (H / 2) * (W / 2);
+  int grid = (int)((total + 255) / 256); if (grid > 16384) grid = 16384;
+  if (dtype == MI355_BF16) hipLaunchKernelGGL(nchw_to_s2d_kernel<bf16_t>, dim3(grid), dim3(256), 0, as_stream(stream), x, (bf16_t*)y, N, H, W);
+  else hipLaunchKernelGGL(nchw_to_s2d_kernel<float>, dim3(grid), dim3(256), 0, as_stream(stream), x, (float*)y, N, H, W);
+  MI_CHECK_LAUNCH("nchw_to_s2d");
+  return MI355_OK;
+}
+
+// w fp32 [Co][7][7][3] (conv-form master) -> out `T` [Co][4][4][16]: the forward operand of the folded stem
+template <typename T>
+__global__ __launch_bounds__(256) void stem_s2d_pack_kernel(const float* __restrict__ w, T* __restrict__ out, int Co) {
+  const int id = blockIdx.x * 256 + threadIdx.x;
+  if (id >= Co * 256) return;
+  const int ch = id & 15, tap = (id >> 4) & 15, o = id >> 8;
+  const int c = ch & 3, dy = ch >> 3, dx = (ch >> 2) & 1;
+  const int kh = 2 * (tap >> 2) + dy - 1, kw = 2 * (tap & 3) + dx - 1;
+  const float v = (c < 3 && kh >= 0 && kh < 7 && kw >= 0 && kw < 7) ? w[((o * 7 + kh) * 7 + kw) * 3 + c] : 0.f;
+  Elem<T>::st(out + id, v);
+}
+// gs fp32 [Co][4][4][16] (weight gradient of the folded form) -> g fp32 [Co][7][7][3] (=, or += when accumulate)
+__global__ __launch_bounds__(256) void stem_s2d_unpack_kernel(const float* __restrict__ gs, float* __restrict__ g, int Co, int accumulate) {
+  const int id = blockIdx.x * 256 + threadIdx.x;
+  if (id >= Co * 147) return;
+  const int c = id % 3, kw = (id / 3) % 7, kh = (id / 21) % 7, o = id / 147;
+  const int th = (kh + 1) >> 1, dy = (kh + 1) & 1, tw = (kw + 1) >> 1, dx = (kw + 1) & 1;
+  const float v = gs[(o * 16 + th * 4 + tw) * 16 + (dy * 2 + dx) * 4 + c];
+  g[id] = accumulate ? g[id] + v : v;
+}
+
+extern "C" int mi355_stem_s2d_pack(const float* w, void* out, int Co, int dtype, void* stream) {
+  if (!w || !out || Co < 1) MI_FAIL(MI355_EINVAL, "stem_s2d_pack: bad args");
+  if (dtype != MI355_BF16 && dtype != MI355_F32) MI_FAIL(MI355_EINVAL, "stem_s2d_pack: dtype %d", dtype);
+  if (dtype == MI355_BF16) hipLaunchKernelGGL(stem_s2d_pack_kernel<bf16_t>, dim3(Co), dim3(256), 0, as_stream(stream), w, (bf16_t*)out, Co);
+  else hipLaunchKernelGGL(stem_s2d_pack_kernel<float>, dim3(Co), dim3(256), 0, as_stream(stream), w, (float*)out, Co);
+  MI_CHECK_LAUNCH("stem_s2d_pack");
+  return MI355_OK;
+}
+extern "C" int mi355_stem_s2d_unpack_grad(const float* gs, float* g, int Co, int accumulate, void* stream) {
+  if (!gs || !g || Co < 1) MI_FAIL(MI355_EINVAL, "stem_s2d_unpack_grad: bad args");
+  hipLaunchKernelGGL(stem_s2d_unpack_kernel, dim3(cdiv((long)Co * 147, 256)), dim3(256), 0, as_stream(stream), gs, g, Co, accumulate);
+  MI_CHECK_LAUNCH("stem_s2d_unpack_grad");
+  return MI355_OK;
+}

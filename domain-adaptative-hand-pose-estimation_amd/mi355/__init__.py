@@ -90,6 +90,9 @@ SIGNATURES = {
     'mi355_maxpool_fwd': (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
     'mi355_maxpool_bwd': (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
     'mi355_nchw_to_nhwc': (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    'mi355_nchw_to_s2d': (_I, [_P, _P, _I, _I, _I, _I, _P]),
+    'mi355_stem_s2d_pack': (_I, [_P, _P, _I, _I, _P]),
+    'mi355_stem_s2d_unpack_grad': (_I, [_P, _P, _I, _I, _P]),
     'mi355_nhwc_to_nchw': (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
     'mi355_conv1x1_heatmap': (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     'mi355_pw_c2k': (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),

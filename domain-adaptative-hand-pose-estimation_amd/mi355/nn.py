@@ -75,10 +75,10 @@ class _FoldedBn:
     def __init__(self):
         self.key, self.w, self.bias = None, None, None
 
-    def get(self, conv, bn, dtype, deconv):
+    def get(self, conv, bn, dtype, deconv, s2d=False):
         ver = lambda t: None if t is None else _param_version(t)
         key = (ver(conv.weight), ver(conv.bias), ver(bn.weight), ver(bn.bias), bn.running_mean._version, bn.running_var._version,
-               _BN_GEN[0], dtype, id(bn), float(bn.eps))
+               _BN_GEN[0], dtype, id(bn), float(bn.eps), s2d)
         if key != self.key:
             with torch.no_grad():
                 scale = bn.weight.detach().float() / torch.sqrt(bn.running_var.float() + bn.eps)
@@ -90,6 +90,8 @@ class _FoldedBn:
                 if deconv:       # conv-form (O = in_channels, I = out_channels): the deconv's OUTPUT channels are I
                     wm = (wm * scale.view(1, 1, 1, -1)).contiguous()
                     _, self.w = ops.pack_weights(wm, conv.in_channels, k2, conv.out_channels, conv.out_channels, dtype, want_f=False, want_t=True)
+                elif s2d:        # the stem in its folded 4x4 form (Conv2d._s2d_ok)
+                    self.w = ops.stem_s2d_pack((wm * scale.view(-1, 1, 1, 1)).contiguous(), dtype)
                 else:
                     wm = (wm * scale.view(-1, 1, 1, 1)).contiguous()
                     self.w, _ = ops.pack_weights(wm, conv.out_channels, k2, conv.in_channels, conv._cin_pad(dtype), dtype, want_f=True, want_t=False)
@@ -123,6 +125,7 @@ def _as_feature(x, dtype):
 _LAZY_MASK = {}
 _LAZY_RES = _os.environ.get('MI355_BN_LAZY_DRES', '1') == '1'      # A/B switch
 _ZERO_BN_BIAS_GRAD = _os.environ.get('MI355_ZERO_BN_BIAS_GRAD', '1') == '1'      # A/B switch (see _bias_grad)
+_STEM_S2D = _os.environ.get('MI355_STEM_S2D', '1') == '1'      # A/B switch: the 7x7 stem as a 4x4 conv over the space-to-depth image
 _BN_POOL_FUSE = _os.environ.get('MI355_BN_POOL_FUSE', '1') == '1'      # A/B switch: stem BatchNorm + ReLU + max-pool in one pass
 
 
@@ -169,6 +172,22 @@ class _PackedWeights:
             self.key = key
             weight._mi_pack = (self, O, T, I, Ipad)        # lets the optimizer refresh all copies of a group in one launch
         return self.wf, self.wt
+
+
+class _PackedS2d:
+    """Forward operand of the stem in its folded form ([Co][4][4][16], ops.stem_s2d_pack), refreshed when the master changes."""
+
+    def __init__(self):
+        self.key, self.wf = None, None
+
+    def get(self, weight, dtype):
+        key = (_param_version(weight), dtype)
+        if key != self.key:
+            if self.wf is None or self.wf.dtype != dtype or self.wf.device != weight.device:
+                self.wf = torch.empty(weight.shape[0] * 256, dtype=dtype, device=weight.device)
+            ops.stem_s2d_pack(weight.detach(), dtype, out=self.wf)
+            self.key = key
+        return self.wf
 
 
 class _PackedFp8:
@@ -942,7 +961,13 @@ class Conv2d(_FastSlots, nn.Module):
         self._last_partial = None
         self._in_bn_src = None
         self.bn_follows = False        # set by link_conv_bn(): the next op is a BatchNorm2d over this conv's output
+        # the torchvision stem (7x7 / stride 2 / pad 3 over 3 channels) runs as a 4x4 conv over the 2x2 space-to-depth image
+        self._s2d = _STEM_S2D and in_channels == 3 and k == 7 and stride == 2 and padding == 3
+        self._packed_s2d = _PackedS2d() if self._s2d else None
         self.reset_parameters()
+
+    def _s2d_ok(self, x):
+        return self._s2d and x.shape[1] == 3 and x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0
 
     def reset_parameters(self):   # nn.Conv2d defaults
         nn.init.kaiming_uniform_(self.weight, a=math.sqrt(5))
@@ -974,6 +999,10 @@ class Conv2d(_FastSlots, nn.Module):
     def _plan(self, x):
         N, C, H, W = x.shape
         k = self.kernel_size[0]
+        if self._s2d and C == 16:       # x is the folded image (ops.to_nhwc_s2d)
+            _chk_convform(self.weight)
+            desc = ops.make_desc(N, H, W, 16, self.out_channels, 4, 4, 1, 2, x.dtype, out_hw=(H, W))
+            return desc, self._packed_s2d.get(self.weight, x.dtype), None
         Cp = self._cin_pad(x.dtype)
         if C != Cp:
             raise Mi355Error('conv expects %d (padded) input channels, got %d' % (Cp, C))
@@ -1020,6 +1049,17 @@ class Conv2d(_FastSlots, nn.Module):
                 _rt.group_wgrad(desc, x, dy, g, acc)
             else:
                 ops.conv_wgrad(desc, x, dy, g, acc)
+        elif desc.kh == 4 and self._s2d:   # folded stem: [Co][4][4][16] gradient, scattered back onto the (Co,3,7,7) one
+            if self._stem_tmp is None or self._stem_tmp.device != x.device or self._stem_tmp.numel() != self.out_channels * 256:
+                self._stem_tmp = torch.empty(self.out_channels * 256, dtype=torch.float32, device=x.device)
+            ops.conv_wgrad(desc, x, dy, self._stem_tmp, False)
+            dst = g.permute(0, 2, 3, 1)
+            if dst.is_contiguous():
+                ops.stem_s2d_unpack_grad(self._stem_tmp, g, acc)
+            else:                          # a gradient tensor in a foreign memory order: torch as glue
+                t = torch.empty(dst.shape, dtype=torch.float32, device=x.device)
+                ops.stem_s2d_unpack_grad(self._stem_tmp, t, False)
+                dst.add_(t) if acc else dst.copy_(t)
         else:   # stem: kernel works on the padded channel count; un-pad into the (Co,3,7,7) gradient
             k = self.kernel_size[0]
             if self._stem_tmp is None or self._stem_tmp.device != x.device:
@@ -1046,16 +1086,18 @@ class Conv2d(_FastSlots, nn.Module):
             if not x.is_cuda:
                 raise Mi355Error('mi355 layers need CUDA/HIP tensors; there is no CPU fallback')
             return _take_partial(self, _PwK2CFn.apply(x, self.weight, self.bias, residual, dtype, self))
-        if x.shape[1] == self.in_channels and self.in_channels != self._cin_pad(dtype):
-            x = ops.to_nhwc(x if (x.dtype == torch.float32 and x.is_contiguous()) else x.float().contiguous(),
-                            dtype, self._cin_pad(dtype))
-        else:
-            x = _as_feature(x, dtype)
+        x = self._input_feature(x, dtype)
         self._in_bn_src = _bn_src_of(x)
         fan = getattr(x, '_mi_fan', None) if torch.is_grad_enabled() and x.requires_grad else None
         return _take_partial(self, _ConvFn.apply(x, self.weight, self.bias, residual, self, scale, fan))
 
     def _input_feature(self, x, dtype):
+        if isinstance(x, _LazyConv):
+            x = x.materialize()
+        if self._s2d_ok(x):
+            if not x.is_cuda:
+                raise Mi355Error('mi355 layers need CUDA/HIP tensors; there is no CPU fallback')
+            return ops.to_nhwc_s2d(x, dtype)
         if x.shape[1] == self.in_channels and self.in_channels != self._cin_pad(dtype):
             return ops.to_nhwc(x if (x.dtype == torch.float32 and x.is_contiguous()) else x.float().contiguous(), dtype, self._cin_pad(dtype))
         return _as_feature(x, dtype)
@@ -1066,8 +1108,12 @@ class Conv2d(_FastSlots, nn.Module):
         x = self._input_feature(x, dtype)
         N, C, H, W = x.shape
         k = self.kernel_size[0]
-        desc = ops.make_desc(N, H, W, C, self.out_channels, k, k, self.stride[0], self.padding[0], x.dtype)
-        wf, bias = self._folded.get(self, bn, dtype, False)
+        s2d = self._s2d and C == 16
+        if s2d:
+            desc = ops.make_desc(N, H, W, 16, self.out_channels, 4, 4, 1, 2, x.dtype, out_hw=(H, W))
+        else:
+            desc = ops.make_desc(N, H, W, C, self.out_channels, k, k, self.stride[0], self.padding[0], x.dtype)
+        wf, bias = self._folded.get(self, bn, dtype, False, s2d=s2d)
         if residual is not None:
             residual = _as_feature(residual, dtype)
         return ops.conv_fwd(desc, x, wf, bias, residual, relu=bool(relu))

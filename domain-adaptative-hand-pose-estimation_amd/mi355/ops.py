@@ -53,9 +53,43 @@ def to_nchw_f32(x):
     return y
 
 
-def make_desc(N, Hi, Wi, Ci, Co, kh, kw, stride, pad, dtype):
+def to_nhwc_s2d(x, dtype=None):
+    """3-channel NCHW fp32 image (even extents) -> the 2x2 space-to-depth image (N, 16, H/2, W/2), channels_last `dtype`: the
+    input of the stem in its folded 4x4 form (mi355_nchw_to_s2d)."""
+    dtype = dtype or compute_dtype()
+    N, C, H, W = x.shape
+    if C != 3 or H % 2 or W % 2:
+        raise Mi355Error('to_nhwc_s2d: a 3-channel image with even extents, got %s' % (tuple(x.shape),))
+    _chk_dev(x)
+    if x.dtype != torch.float32 or not x.is_contiguous():
+        x = x.float().contiguous()
+    y = nhwc_empty(N, 16, H // 2, W // 2, dtype, x.device)
+    call('mi355_nchw_to_s2d', ptr(x), ptr(y), N, H, W, dtype_code(dtype), stream_ptr())
+    return y
+
+
+def stem_s2d_pack(w, dtype, out=None):
+    """w: fp32 [Co][7][7][3] memory order -> flat `dtype` [Co][4][4][16], the folded stem's forward operand."""
+    _chk_dev(w)
+    Co = w.numel() // 147
+    if out is None:
+        out = torch.empty(Co * 256, dtype=dtype, device=w.device)
+    call('mi355_stem_s2d_pack', ptr(w), ptr(out), Co, dtype_code(dtype), stream_ptr())
+    return out
+
+
+def stem_s2d_unpack_grad(gs, g, accumulate):
+    """gs: fp32 [Co][4][4][16] weight gradient of the folded stem; g: fp32 gradient in [Co][7][7][3] memory order (= / +=)."""
+    _chk_dev(gs, g)
+    call('mi355_stem_s2d_unpack_grad', ptr(gs), ptr(g), g.numel() // 147, int(bool(accumulate)), stream_ptr())
+
+
+def make_desc(N, Hi, Wi, Ci, Co, kh, kw, stride, pad, dtype, out_hw=None):
+    """out_hw: (Ho, Wo) of a cropped output (unit stride; forward and weight gradient only)."""
     Ho = (Hi + 2 * pad - kh) // stride + 1
     Wo = (Wi + 2 * pad - kw) // stride + 1
+    if out_hw is not None:
+        Ho, Wo = out_hw
     return ConvDesc(N, Hi, Wi, Ci, Ho, Wo, Co, kh, kw, stride, pad, dtype_code(dtype))
 
 

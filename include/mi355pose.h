@@ -46,7 +46,8 @@ extern "C" {
 
 typedef struct {
   int N, Hi, Wi, Ci; /* conv-form input  (NHWC)                       */
-  int Ho, Wo, Co;    /* conv-form output (NHWC)                       */
+  int Ho, Wo, Co;    /* conv-form output (NHWC); = (Hi + 2 pad - kh) / stride + 1, or -- unit stride, mi355_conv_fwd* and
+                        mi355_conv_wgrad only -- any smaller size: the top-left Ho x Wo crop of that output */
   int kh, kw, stride, pad;
   int dtype;         /* MI355_F32 | MI355_BF16 (activations+packed weights) | MI355_FP8 (mi355_conv_*_fp8 only) */
 } mi355_conv_desc;
@@ -284,6 +285,15 @@ int mi355_maxpool_bwd(const void* dy, const uint8_t* argidx, void* dx, int N, in
 /* ---------------------------------------------------------------- layout changes at the API edge */
 /* image / feature NCHW fp32 -> NHWC `dtype` with channels zero-padded to Cpad (stem input). */
 int mi355_nchw_to_nhwc(const float* x, void* y, int N, int C, int H, int W, int Cpad, int dtype, void* stream);
+/* The stem (resnet.py:23-28: Conv2d(3, 64, 7, stride 2, padding 3)) as a 4x4 / unit-stride conv over the image folded 2x2 into
+ * channels: y [N][H/2][W/2][16] `dtype`, folded channel (dy*2 + dx)*4 + c (c = 3 zero), H and W even.  The conv then runs through
+ * mi355_conv_fwd* / mi355_conv_wgrad with the descriptor {Hi = H/2, Wi = W/2, Ci = 16, kh = kw = 4, stride 1, pad 2, Ho = H/2,
+ * Wo = W/2}: those entry points accept the top-left Ho x Wo crop of a unit-stride conv's output.  K = 256 instead of 49 x 8 = 392. */
+int mi355_nchw_to_s2d(const float* x, void* y, int N, int H, int W, int dtype, void* stream);
+/* stem weights fp32 [Co][7][7][3] -> folded forward operand `dtype` [Co][4][4][16]; and the folded weight gradient fp32
+ * [Co][4][4][16] back onto g fp32 [Co][7][7][3] (g = / += per `accumulate`). */
+int mi355_stem_s2d_pack(const float* w, void* out, int Co, int dtype, void* stream);
+int mi355_stem_s2d_unpack_grad(const float* gs, float* g, int Co, int accumulate, void* stream);
 /* NHWC `dtype` -> NCHW fp32 (the feature map `f` returned by PoseResNetx9.forward, regda_7.py:4944). */
 int mi355_nhwc_to_nchw(const void* x, float* y, int N, int C, int H, int W, int dtype, void* stream);
 

@@ -113,6 +113,56 @@ def test_conv_fwd_dgrad_wgrad(gpu, dt, case):
 
 
 @pytest.mark.parametrize('dt', ['f32', 'bf16'])
+@pytest.mark.parametrize('shape', [(2, 32, 32), (3, 20, 36), (64, 256, 256)])
+def test_stem_as_4x4_conv_over_the_space_to_depth_image(gpu, dt, shape):
+    """Conv2d(3, 64, 7, stride 2, padding 3) (reference resnet.py:23-28) in its folded form: mi355_nchw_to_s2d + mi355_stem_s2d_pack
+    + the cropped 4x4 / unit-stride descriptor + mi355_stem_s2d_unpack_grad, against torch's 7x7 conv (forward, BatchNorm
+    statistics of the output, weight gradient with and without accumulation); the last shape is the benchmark's."""
+    ops = _ops()
+    N, H, W = shape
+    Co = 64
+    x = _round(randn(61, N, 3, H, W), dt)
+    w = _round(randn(62, Co, 3, 7, 7, scale=1.0 / np.sqrt(147)), dt)
+    y_ref = F.conv2d(x, w, None, stride=2, padding=3)
+    dy = _round(randn(63, *y_ref.shape), dt)
+    wr = w.clone().requires_grad_(True)
+    F.conv2d(x, wr, None, stride=2, padding=3).backward(dy)
+    dw_ref = wr.grad.permute(0, 2, 3, 1).contiguous()
+
+    xs = ops.to_nhwc_s2d(x.to(gpu), DT[dt])
+    assert tuple(xs.shape) == (N, 16, H // 2, W // 2)
+    fold = x.view(N, 3, H // 2, 2, W // 2, 2).permute(0, 3, 5, 1, 2, 4)              # [N][dy][dx][c][by][bx]
+    ref_s = torch.zeros(N, 2, 2, 4, H // 2, W // 2); ref_s[:, :, :, :3] = fold
+    assert torch.equal(_back(xs), ref_s.reshape(N, 16, H // 2, W // 2))
+    wm = w.permute(0, 2, 3, 1).contiguous().to(gpu)
+    wf = ops.stem_s2d_pack(wm, DT[dt])
+    desc = ops.make_desc(N, H // 2, W // 2, 16, Co, 4, 4, 1, 2, DT[dt], out_hw=(H // 2, W // 2))
+    y, part = ops.conv_fwd_stats(desc, xs, wf, None)
+    assert tuple(y.shape) == tuple(y_ref.shape)
+    assert float((_back(y) - y_ref).abs().max()) <= _tol(dt, y_ref)
+    assert part is not None and part[1] >= 1
+    outs = []
+    for pp in (None, part):             # BatchNorm from the epilogue's partials == BatchNorm with its own statistics pass
+        rm, rv = torch.zeros(Co, device=gpu), torch.ones(Co, device=gpu)
+        nbt = torch.zeros((), dtype=torch.int64, device=gpu)
+        outs.append(ops.bn_train_fwd(y, None, torch.ones(Co, device=gpu), torch.zeros(Co, device=gpu), rm, rv, nbt, 1e-5, 0.1, True, partial=pp))
+    assert torch.allclose(outs[0][1], outs[1][1], rtol=1e-5, atol=1e-6) and torch.allclose(outs[0][2], outs[1][2], rtol=2e-5, atol=1e-6)
+
+    dyd = _nhwc(dy, dt, gpu)
+    gs = torch.empty(Co * 256, dtype=torch.float32, device=gpu)
+    ops.conv_wgrad(desc, xs, dyd, gs, accumulate=False)
+    g = torch.full((Co, 7, 7, 3), 3.0, dtype=torch.float32, device=gpu)
+    ops.stem_s2d_unpack_grad(gs, g, False)
+    assert float((g.cpu() - dw_ref).abs().max()) <= _tol(dt, dw_ref)
+    ops.stem_s2d_unpack_grad(gs, g, True)
+    assert float((g.cpu() - 2 * dw_ref).abs().max()) <= 2 * _tol(dt, dw_ref)
+    # the positions of the folded gradient that correspond to no 7x7 tap are exactly the products with the zero channel / the
+    # kh = -1 row: they are computed (the image is not zero there) but never read back
+    with pytest.raises(Exception):      # a cropped descriptor stays refused where it has no meaning (input gradient)
+        ops.conv_dgrad(desc, dyd, wf)
+
+
+@pytest.mark.parametrize('dt', ['f32', 'bf16'])
 def test_conv_residual_epilogue(gpu, dt):
     ops = _ops()
     N, Ci, H, W, Co = 2, 64, 8, 8, 128
