@@ -173,9 +173,12 @@ class DAStep:
     def _overlap_capturable(self):
         """Can the overlapped exchange be CAPTURED into the HIP graphs?  RCCL collectives are stream work and capture like kernels
         (probed on this stack: scratch/rccl_graph_probe.py -- an async all-reduce on RCCL's stream inside torch.cuda.graph, replayed);
-        gloo collectives are host work and cannot.  MI355_DDP_GRAPH_OVERLAP=0 keeps the blocking exchange between the graphs."""
+        gloo collectives are host work and cannot.  OPT-IN (MI355_DDP_GRAPH_OVERLAP=1): the default keeps the blocking exchange
+        between the graphs -- on one xGMI node the two forms are expected within a few tenths of a millisecond of each other
+        (DESIGN.md section 6), the captured form has only ever run in a one-rank group (no multi-GPU box in this build's reach), and
+        a capture that hangs on real ranks would cost a whole run, where an exception only costs a fallback."""
         return (self.overlap and _distributed() and dist.get_backend() == 'nccl' and
-                os.environ.get('MI355_DDP_GRAPH_OVERLAP', '1') == '1')
+                os.environ.get('MI355_DDP_GRAPH_OVERLAP', '0') == '1')
 
     def _begin_reduce(self, keys):
         """Arm the overlapped reducer for the backward about to run: more than one rank, launched eagerly -- or being captured with
