@@ -1665,6 +1665,7 @@ static WgradPlan plan_wgrad(const mi355_conv_desc* d) {
   // 3x3 / stride 1 / pad 1 in bf16 with a power-of-two width: the kw-shared kernel (see wgrad_kw_kernel)
   static const int kw3_on = getenv("MI355_WGRAD_KW") ? atoi(getenv("MI355_WGRAD_KW")) : 1;
   w.kw3 = kw3_on && d->dtype == MI355_BF16 && d->kh == 3 && d->kw == 3 && d->stride == 1 && d->pad == 1 &&
+          d->Ho == d->Hi && d->Wo == d->Wi &&              // (not a cropped output: the shifted-row trick needs same-size maps)
           d->Wi >= 8 && ilog2_exact(d->Wi) >= 0;
   w.mt = d->Co <= 64 ? 1 : 2;
   // 3x3 / 4x4, stride 2, pad 1 in bf16, output width a power of two in [8, 64]: the parity-image kernel (wgrad_kw2_kernel)

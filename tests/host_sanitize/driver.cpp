@@ -97,6 +97,36 @@ int main() {
     mi355_conv_desc d = desc(2, 16, 16, 64, 64, 3, 1, 1, MI355_BF16);
     mi355_conv_desc b = d; b.Ho += 1;
     EXPECT(mi355_conv_fwd(&b, fake(1), fake(2), nullptr, nullptr, fake(3), nullptr) == MI355_EINVAL);
+    // cropped outputs (top-left Ho x Wo of a unit-stride conv): forward and weight gradient take them, the input gradient and every
+    // strided / 1x1 / fp8 descriptor do not; the folded stem's descriptor (4x4 over the 128 x 128 x 16 space-to-depth image) is one
+    b = d; b.Ho -= 3; b.Wo -= 1;
+    int rcc = mi355_conv_fwd(&b, fake(1), fake(2), nullptr, nullptr, fake(3), nullptr);
+    EXPECT(rcc == MI355_ELAUNCH || rcc == MI355_OK);
+    rcc = mi355_conv_wgrad(&b, fake(1), fake(3), (float*)fake(7), 0, fake(8), mi355_conv_wgrad_workspace(&b), nullptr);
+    EXPECT(rcc == MI355_ELAUNCH || rcc == MI355_OK);
+    EXPECT(mi355_conv_dgrad(&b, fake(3), fake(2), nullptr, nullptr, 0, fake(1), nullptr) == MI355_EINVAL);
+    b = desc(2, 16, 16, 64, 64, 3, 2, 1, MI355_BF16); b.Ho -= 1;
+    EXPECT(mi355_conv_fwd(&b, fake(1), fake(2), nullptr, nullptr, fake(3), nullptr) == MI355_EINVAL);
+    b = desc(2, 16, 16, 64, 64, 1, 1, 0, MI355_BF16); b.Ho -= 1;
+    EXPECT(mi355_conv_fwd(&b, fake(1), fake(2), nullptr, nullptr, fake(3), nullptr) == MI355_EINVAL);
+    for (int dt = MI355_F32; dt <= MI355_BF16; ++dt) {
+      b = desc(64, 128, 128, 16, 64, 4, 1, 2, dt); b.Ho = b.Wo = 128;
+      int ns = -1;
+      rcc = mi355_conv_fwd_stats(&b, fake(1), fake(2), nullptr, fake(3), (float*)fake(5), mi355_conv_stats_bytes(64L * 128 * 128, 64), &ns, nullptr);
+      EXPECT(rcc == MI355_ELAUNCH || rcc == MI355_OK);
+      rcc = mi355_conv_wgrad(&b, fake(1), fake(3), (float*)fake(7), 0, fake(8), mi355_conv_wgrad_workspace(&b), nullptr);
+      EXPECT(rcc == MI355_ELAUNCH || rcc == MI355_OK);
+      rcc = mi355_nchw_to_s2d((const float*)fake(1), fake(2), 64, 256, 256, dt, nullptr);
+      EXPECT(rcc == MI355_ELAUNCH || rcc == MI355_OK);
+      rcc = mi355_stem_s2d_pack((const float*)fake(1), fake(2), 64, dt, nullptr);
+      EXPECT(rcc == MI355_ELAUNCH || rcc == MI355_OK);
+    }
+    rcc = mi355_stem_s2d_unpack_grad((const float*)fake(1), (float*)fake(2), 64, 1, nullptr);
+    EXPECT(rcc == MI355_ELAUNCH || rcc == MI355_OK);
+    EXPECT(mi355_nchw_to_s2d((const float*)fake(1), fake(2), 2, 255, 256, MI355_BF16, nullptr) == MI355_EINVAL);      // odd extent
+    EXPECT(mi355_nchw_to_s2d((const float*)fake(1), fake(2), 2, 256, 256, MI355_FP8, nullptr) == MI355_EINVAL);
+    EXPECT(mi355_stem_s2d_pack(nullptr, fake(2), 64, MI355_BF16, nullptr) == MI355_EINVAL);
+    EXPECT(mi355_stem_s2d_unpack_grad((const float*)fake(1), nullptr, 64, 0, nullptr) == MI355_EINVAL);
     b = d; b.stride = 3;
     EXPECT(mi355_conv_fwd(&b, fake(1), fake(2), nullptr, nullptr, fake(3), nullptr) == MI355_EINVAL);
     b = d; b.kh = b.kw = 9;

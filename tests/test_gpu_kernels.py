@@ -163,6 +163,35 @@ def test_stem_as_4x4_conv_over_the_space_to_depth_image(gpu, dt, shape):
 
 
 @pytest.mark.parametrize('dt', ['f32', 'bf16'])
+@pytest.mark.parametrize('case', [(2, 64, 16, 16, 128, 3, 1, 13, 11), (1, 64, 9, 20, 64, 4, 2, 9, 20), (2, 128, 8, 8, 64, 5, 2, 5, 7)])
+def test_cropped_output_descriptor(gpu, dt, case):
+    """Ho x Wo smaller than the full output of a unit-stride conv = its top-left crop, in the forward and the weight gradient (the
+    3x3 case must NOT take the shifted-row weight-gradient kernel, which needs same-size maps); the input gradient refuses it."""
+    ops = _ops()
+    N, Ci, H, W, Co, k, p, Ho, Wo = case
+    x = _round(randn(71, N, Ci, H, W), dt)
+    w = _round(randn(72, Co, Ci, k, k, scale=1.0 / np.sqrt(Ci * k * k)), dt)
+    wr = w.clone().requires_grad_(True)
+    y_full = F.conv2d(x, wr, None, stride=1, padding=p)
+    assert Ho <= y_full.shape[2] and Wo <= y_full.shape[3]
+    y_ref = y_full[:, :, :Ho, :Wo]
+    dy = _round(randn(73, *y_ref.shape), dt)
+    y_ref.backward(dy)
+    desc = ops.make_desc(N, H, W, Ci, Co, k, k, 1, p, DT[dt], out_hw=(Ho, Wo))
+    xd = _nhwc(x, dt, gpu)
+    wf, wt = ops.pack_weights(w.permute(0, 2, 3, 1).contiguous().to(gpu), Co, k * k, Ci, Ci, DT[dt])
+    y = ops.conv_fwd(desc, xd, wf, None)
+    assert tuple(y.shape) == tuple(y_ref.shape)
+    assert float((_back(y) - y_ref.detach()).abs().max()) <= _tol(dt, y_ref.detach())
+    dw = torch.empty((Co, k, k, Ci), dtype=torch.float32, device=gpu)
+    ops.conv_wgrad(desc, xd, _nhwc(dy, dt, gpu), dw, accumulate=False)
+    dw_ref = wr.grad.permute(0, 2, 3, 1)
+    assert float((dw.cpu() - dw_ref).abs().max()) <= _tol(dt, dw_ref)
+    with pytest.raises(Exception):
+        ops.conv_dgrad(desc, _nhwc(dy, dt, gpu), wt)
+
+
+@pytest.mark.parametrize('dt', ['f32', 'bf16'])
 def test_conv_residual_epilogue(gpu, dt):
     ops = _ops()
     N, Ci, H, W, Co = 2, 64, 8, 8, 128
