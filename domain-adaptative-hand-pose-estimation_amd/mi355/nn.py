@@ -86,6 +86,8 @@ class _FoldedBn:
                 if conv.bias is not None:
                     shift = shift + conv.bias.detach().float() * scale
                 wm = conv.weight.detach().permute(0, 2, 3, 1)            # memory order [O][kh][kw][I], contiguous view
+                if getattr(conv, 'groups', 1) > 1:
+                    wm = _dense_from_grouped(conv.weight, conv.groups)   # dense block-diagonal [O][kh][kw][in_channels]
                 k2 = conv.kernel_size[0] * conv.kernel_size[1]
                 if deconv:       # conv-form (O = in_channels, I = out_channels): the deconv's OUTPUT channels are I
                     wm = (wm * scale.view(1, 1, 1, -1)).contiguous()
@@ -171,6 +173,33 @@ class _PackedWeights:
             ops.pack_weights_into(weight.detach(), self.wf, self.wt, O, T, I, Ipad, dtype)
             self.key = key
             weight._mi_pack = (self, O, T, I, Ipad)        # lets the optimizer refresh all copies of a group in one launch
+        return self.wf, self.wt
+
+
+def _dense_from_grouped(w, groups):
+    """Grouped conv-form weight (Co, Ci/g, kh, kw) -> fp32 dense block-diagonal master [Co][kh][kw][Ci] (zeros off the diagonal)."""
+    Co, cig, kh, kw = w.shape
+    cog = Co // groups
+    wm = w.detach().permute(0, 2, 3, 1).reshape(groups, cog, kh, kw, cig).float()       # conv-form memory: a view
+    dense = torch.zeros(groups, cog, kh, kw, groups, cig, dtype=torch.float32, device=w.device)
+    idx = torch.arange(groups, device=w.device)
+    dense[idx, :, :, :, idx, :] = wm
+    return dense.view(Co, kh, kw, groups * cig)
+
+
+class _PackedGrouped:
+    """Forward / input-gradient operands of a grouped conv (ResNeXt): the dense block-diagonal weight, packed like any other.  The
+    kernels have no grouped form -- a group of 4 ... 32 channels is far below an MFMA tile -- so the zeros are multiplied too."""
+
+    def __init__(self):
+        self.key, self.wf, self.wt = None, None, None
+
+    def get(self, weight, groups, dtype):
+        key = (_param_version(weight), dtype)
+        if key != self.key:
+            Co, cig, kh, kw = weight.shape
+            self.wf, self.wt = ops.pack_weights(_dense_from_grouped(weight, groups), Co, kh * kw, groups * cig, groups * cig, dtype)
+            self.key = key
         return self.wf, self.wt
 
 
@@ -945,12 +974,16 @@ class Conv2d(_FastSlots, nn.Module):
     1x1 convs to / from the K-channel heat-maps (K not a multiple of the 16-byte chunk) take the
     dedicated point-wise kernels and exchange NCHW fp32 heat-maps."""
 
-    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, bias=True):
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, bias=True, groups=1):
         super().__init__()
         k = kernel_size if isinstance(kernel_size, int) else kernel_size[0]
-        self.in_channels, self.out_channels = in_channels, out_channels
+        if groups < 1 or in_channels % groups or out_channels % groups:
+            raise ValueError('in_channels and out_channels must be divisible by groups')
+        self.in_channels, self.out_channels, self.groups = in_channels, out_channels, groups
         self.kernel_size, self.stride, self.padding = (k, k), (stride, stride), (padding, padding)
-        self.weight = _convform_param(out_channels, in_channels, k, k)
+        self.weight = _convform_param(out_channels, in_channels // groups, k, k)
+        self._packed_g = _PackedGrouped() if groups > 1 else None
+        self._g_tmp = None
         self.bias = nn.Parameter(torch.empty(out_channels)) if bias else None
         self._packed = _PackedWeights()
         self._packed8, self._q_in, self._q_dy = _PackedFp8(), _Fp8Stream(ops.E4M3), _Fp8Stream(_GRAD_FMT)
@@ -972,16 +1005,19 @@ class Conv2d(_FastSlots, nn.Module):
     def reset_parameters(self):   # nn.Conv2d defaults
         nn.init.kaiming_uniform_(self.weight, a=math.sqrt(5))
         if self.bias is not None:
-            fan_in = self.in_channels * self.kernel_size[0] * self.kernel_size[1]
+            fan_in = self.in_channels // self.groups * self.kernel_size[0] * self.kernel_size[1]
             bound = 1 / math.sqrt(fan_in) if fan_in > 0 else 0
             nn.init.uniform_(self.bias, -bound, bound)
 
     def extra_repr(self):
-        return '{in_channels}, {out_channels}, kernel_size={kernel_size}, stride={stride}, padding={padding}'.format(**self.__dict__)
+        return ('{in_channels}, {out_channels}, kernel_size={kernel_size}, stride={stride}, padding={padding}'.format(**self.__dict__) +
+                (', groups=%d' % self.groups if self.groups > 1 else ''))
 
     @property
     def mode(self):
         k = self.kernel_size[0]
+        if self.groups > 1:
+            return 'mfma'
         if k == 1 and self.stride[0] == 1 and self.out_channels % 8 and self.out_channels <= 32:
             return 'c2k'
         if k == 1 and self.stride[0] == 1 and self.in_channels % 8 and self.in_channels <= 32 and self.in_channels > 3:
@@ -1008,13 +1044,18 @@ class Conv2d(_FastSlots, nn.Module):
             raise Mi355Error('conv expects %d (padded) input channels, got %d' % (Cp, C))
         _chk_convform(self.weight)
         desc = ops.make_desc(N, H, W, Cp, self.out_channels, k, k, self.stride[0], self.padding[0], x.dtype)
+        if self.groups > 1:
+            if Cp != self.in_channels:
+                raise Mi355Error('grouped conv: in_channels must be a multiple of the 16-byte chunk')
+            wf, wt = self._packed_g.get(self.weight, self.groups, x.dtype)
+            return desc, wf, wt
         wf, wt = self._packed.get(self.weight, self.out_channels, k * k, self.in_channels, Cp, x.dtype)
         return desc, wf, wt
 
     def _fp8_ok(self, x):
         """fp8 operands for this conv?  'fp8' compute mode, a K-heavy kernel (3x3 and up: the 1x1 convs are HBM-bound, an
         extra quantisation pass would cost more than the GEMM gains) and channel counts the fp8 K tile (128) divides."""
-        if not (_rt.fp8_convs() and (self.training or _FP8_EVAL) and self.mode == 'mfma' and x.dtype == torch.bfloat16 and
+        if not (_rt.fp8_convs() and (self.training or _FP8_EVAL) and self.mode == 'mfma' and self.groups == 1 and x.dtype == torch.bfloat16 and
                 self.in_channels % 128 == 0 and self.out_channels % 128 == 0):
             return False
         # a 1x1 conv is HBM-bound: worth it only when its producer already wrote the fp8 copy of x (BatchNorm side output)
@@ -1044,6 +1085,18 @@ class Conv2d(_FastSlots, nn.Module):
 
     def _wgrad(self, desc, x, dy, weight):
         g, acc = grad_slot(weight)
+        if self.groups > 1:     # dense gradient [Co][kh][kw][Ci], then its block diagonal onto the grouped (Co, Ci/g, kh, kw) gradient
+            k, G = self.kernel_size[0], self.groups
+            n = self.out_channels * k * k * self.in_channels
+            if self._g_tmp is None or self._g_tmp.device != x.device or self._g_tmp.numel() != n:
+                self._g_tmp = torch.empty(n, dtype=torch.float32, device=x.device)
+            ops.conv_wgrad(desc, x, dy, self._g_tmp, False)
+            idx = torch.arange(G, device=x.device)
+            diag = self._g_tmp.view(G, self.out_channels // G, k, k, G, self.in_channels // G)[idx, :, :, :, idx, :]
+            dst = g.permute(0, 2, 3, 1)
+            src = diag.reshape(self.out_channels, k, k, self.in_channels // G)
+            dst.add_(src) if acc else dst.copy_(src)
+            return
         if desc.Ci == self.in_channels:
             if _rt.grouping_wgrads():
                 _rt.group_wgrad(desc, x, dy, g, acc)

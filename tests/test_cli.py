@@ -67,3 +67,26 @@ def test_train_resume_and_test_cli_on_gpu(gpu, tmp_path):
     assert 'Epoch: [1]' in out and 'Epoch: [0]' not in out
     out = run('test.py', ['--checkpoint', ck_path])
     assert 'Source:' in out and 'fingertip:' in out
+
+
+def test_resnext_and_wide_resnet_constructors_keep_the_torchvision_state_dict_layout():
+    """reference uda/model/resnet.py:124-183 (resnext50_32x4d, resnext101_32x8d, wide_resnet50_2, wide_resnet101_2 pass `groups` /
+    `width_per_group` to torchvision's ResNet): parameter names and shapes as torchvision's (known shapes of its Bottleneck, v1.5)."""
+    import uda.model as models
+    assert {'resnext50_32x4d', 'resnext101_32x8d', 'wide_resnet50_2', 'wide_resnet101_2'} <= set(models.__all__)
+    sd = models.resnext50_32x4d().state_dict()
+    assert tuple(sd['layer1.0.conv1.weight'].shape) == (128, 64, 1, 1)
+    assert tuple(sd['layer1.0.conv2.weight'].shape) == (128, 4, 3, 3)          # 32 groups x 4 channels
+    assert tuple(sd['layer1.0.conv3.weight'].shape) == (256, 128, 1, 1)
+    assert tuple(sd['layer4.2.conv2.weight'].shape) == (1024, 32, 3, 3)
+    assert tuple(sd['layer4.0.downsample.0.weight'].shape) == (2048, 1024, 1, 1) and tuple(sd['fc.weight'].shape) == (1000, 2048)
+    sd = models.resnext101_32x8d().state_dict()
+    assert tuple(sd['layer1.0.conv2.weight'].shape) == (256, 8, 3, 3) and tuple(sd['layer3.22.conv2.weight'].shape) == (1024, 32, 3, 3)
+    sd = models.wide_resnet50_2().state_dict()
+    assert tuple(sd['layer1.0.conv2.weight'].shape) == (128, 128, 3, 3) and tuple(sd['layer4.2.conv1.weight'].shape) == (1024, 2048, 1, 1)
+    assert tuple(sd['layer4.2.conv3.weight'].shape) == (2048, 1024, 1, 1)
+    m = models.wide_resnet101_2()
+    assert len(m.layer3) == 23 and m.out_features == 2048
+    assert len(models.resnet50().state_dict()) == len(models.wide_resnet50_2().state_dict()) == len(models.resnext50_32x4d().state_dict())
+    with pytest.raises(ValueError):
+        models.ResNet(models.resnet.BasicBlock, [2, 2, 2, 2], groups=32, width_per_group=4)

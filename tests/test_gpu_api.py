@@ -362,3 +362,75 @@ def test_eval_forward_folds_batchnorm_and_replays_from_a_graph(gpu, dt):
             assert torch.equal(fwd(x), y_new) and not torch.equal(y_new, y_fold)
     finally:
         mi355.set_compute_dtype('f32')
+
+
+@pytest.mark.parametrize('case', [(2, 128, 16, 16, 128, 3, 1, 32), (3, 256, 8, 8, 256, 3, 2, 32), (2, 64, 12, 12, 128, 3, 1, 4)])
+def test_grouped_conv_layer_matches_torch(gpu, case):
+    """mi355.nn.Conv2d(groups = g) -- the 3x3 conv of a ResNeXt bottleneck (reference resnet.py:124-149 via torchvision's
+    `groups`) -- against F.conv2d(groups = g) in fp32: output, input gradient, weight gradient in the grouped (Co, Ci/g, 3, 3) layout
+    (first backward overwrites, second accumulates), eval-mode forward with the BatchNorm that follows folded in."""
+    import torch.nn.functional as F
+    from mi355 import nn as mnn
+    N, Ci, H, W, Co, k, s, G = case
+    conv = mnn.Conv2d(Ci, Co, k, s, 1, bias=False, groups=G).to(gpu)
+    assert tuple(conv.weight.shape) == (Co, Ci // G, k, k)
+    w = randn(91, Co, Ci // G, k, k, scale=1.0 / np.sqrt(Ci // G * k * k))
+    with torch.no_grad():
+        conv.weight.copy_(w.to(gpu))
+    x = randn(92, N, Ci, H, W)
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    y_ref = F.conv2d(xr, wr, None, stride=s, padding=1, groups=G)
+    dy = randn(93, *y_ref.shape)
+    y_ref.backward(dy)
+    from mi355 import ops
+    xd = ops.to_nhwc(x.to(gpu), torch.float32).detach().requires_grad_(True)      # a feature map as the layers exchange them (channels_last)
+    y = conv(xd)
+    assert float((y.detach().float().cpu() - y_ref.detach()).abs().max()) <= 1e-3 * float(y_ref.detach().abs().max())
+    y.backward(dy.to(gpu))
+    assert float((xd.grad.float().cpu() - xr.grad).abs().max()) <= 1e-3 * float(xr.grad.abs().max())
+    assert tuple(conv.weight.grad.shape) == (Co, Ci // G, k, k)
+    assert float((conv.weight.grad.cpu() - wr.grad).abs().max()) <= 1e-3 * float(wr.grad.abs().max())
+    conv(xd).backward(dy.to(gpu))                        # second backward: accumulates
+    assert float((conv.weight.grad.cpu() - 2 * wr.grad).abs().max()) <= 2e-3 * float(wr.grad.abs().max())
+    # inference: conv -> eval-mode BatchNorm -> ReLU as one launch on the dense block-diagonal weights
+    bn = mnn.BatchNorm2d(Co).to(gpu)
+    with torch.no_grad():
+        bn.running_mean.copy_(randn(94, Co, scale=0.1).to(gpu)); bn.running_var.copy_((1 + 0.2 * rand(95, Co)).to(gpu))
+        bn.weight.copy_((1 + 0.1 * randn(96, Co)).to(gpu)); bn.bias.copy_((0.1 * randn(97, Co)).to(gpu))
+    seq = mnn.FusedSequential(conv, bn, mnn.ReLU()).eval()
+    mnn.link_conv_bn(seq)
+    with torch.no_grad():
+        z = seq(x.to(gpu))
+        z_ref = F.relu(F.batch_norm(y_ref.detach(), bn.running_mean.cpu(), bn.running_var.cpu(), bn.weight.cpu(), bn.bias.cpu(), False, 0.0, bn.eps))
+    assert float((z.float().cpu() - z_ref).abs().max()) <= 1e-3 * float(z_ref.abs().max())
+
+
+@pytest.mark.parametrize('arch', ['resnext50_32x4d', 'wide_resnet50_2'])
+def test_resnext_and_wide_resnet_backbones_train_through_the_pose_model(gpu, arch):
+    """The constructors the reference re-exports beside resnet50 / resnet101 (resnet.py:124-183) plug into PoseResNetx9 like those:
+    out_features 2048, one step-A forward + backward leaves a finite gradient on every backbone conv (grouped ones in their
+    grouped layout), and the eval forward agrees with the train-mode graph's shapes."""
+    import uda.model as models
+    from uda.model.pose_resnet2 import Upsampling
+    from uda.model.regda_7 import PoseResNetx9
+    bb = models.__dict__[arch](pretrained=False)
+    assert bb.out_features == 2048
+    model = PoseResNetx9(bb, Upsampling(bb.out_features), 256, 21, num_head_layers=2, finetune=True)
+    fill_module_(model, 901)
+    model = model.to(gpu).train()
+    x = randn(902, 2, 3, 128, 128).to(gpu)
+    y, y_adv, y_adv2, y_adv3, f = model(x)
+    assert tuple(y.shape) == (2, 21, 32, 32) and tuple(f.shape)[1] == 256
+    (y.square().mean() + y_adv.square().mean()).backward()
+    for name, p in model.backbone.named_parameters():
+        if name.startswith('fc.'):
+            continue
+        assert p.grad is not None and tuple(p.grad.shape) == tuple(p.shape) and bool(torch.isfinite(p.grad).all()), name
+    if arch.startswith('resnext'):
+        assert tuple(model.backbone.layer2[1].conv2.weight.shape) == (256, 8, 3, 3)
+        assert float(model.backbone.layer2[1].conv2.weight.grad.abs().sum()) > 0
+    model.eval()
+    with torch.no_grad():
+        ye = model(x)
+    ye = ye[0] if isinstance(ye, (tuple, list)) else ye
+    assert tuple(ye.shape) == (2, 21, 32, 32) and bool(torch.isfinite(ye).all())
