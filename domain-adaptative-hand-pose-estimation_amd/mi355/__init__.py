@@ -195,6 +195,22 @@ def set_compute_dtype(dt):
         raise ValueError('compute dtype must be bf16, f32 or fp8, got %r' % (dt,))
 
 
+def graph_capture_mode():
+    """`capture_error_mode` for torch.cuda.graph on this process.  With an RCCL ('nccl') process group initialised, the group's
+    watchdog thread polls the events of earlier collectives with hipEventQuery; a capture in the default 'global' mode forbids that
+    call to EVERY thread, the watchdog dies with hipErrorStreamCaptureUnsupported and std::terminate takes the process with it (a
+    race, seen once in tests/rccl_single_rank.py).  'thread_local' restricts the check to the capturing thread; the device is
+    drained and the watchdog given a moment to retire what is pending.  Without such a group: the default."""
+    import torch
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_backend() == 'nccl':
+        import time
+        torch.cuda.synchronize()
+        time.sleep(0.2)
+        return 'thread_local'
+    return 'global'
+
+
 def compute_dtype():
     """Storage / kernel dtype of activations (bf16 in 'fp8' mode as well)."""
     return _compute_dtype

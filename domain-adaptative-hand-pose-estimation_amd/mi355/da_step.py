@@ -366,17 +366,7 @@ class DAStep:
         else:
             seg_a, seg_b, seg_c = (lambda: self._fwdbwd_A(self.static)), (lambda: self._fwdbwd_B(self.static)), (lambda: self._fwdbwd_C(self.static))
         segs = [seg_a, self._update_A, seg_b, self._update_B, seg_c, lambda: (self._update_C(), self._accuracy(self.static))]
-        # With collectives in the capture the process group's watchdog thread is alive beside it: it polls the events of earlier
-        # (eager) collectives with hipEventQuery, which a capture in the default 'global' error mode forbids to EVERY thread -- the
-        # watchdog then dies with hipErrorStreamCaptureUnsupported and takes the process with it (seen once in
-        # tests/rccl_single_rank.py, a race).  'thread_local' restricts the check to the capturing thread; the device is also
-        # drained first so that the watchdog can retire what is pending.
-        mode = 'global'
-        if self.exchange_captured:
-            import time
-            mode = 'thread_local'
-            torch.cuda.synchronize()
-            time.sleep(0.2)
+        mode = _rt.graph_capture_mode()        # 'thread_local' beside an RCCL process group (its watchdog thread polls events)
         graphs = []
         for fn in segs:
             g = torch.cuda.CUDAGraph()

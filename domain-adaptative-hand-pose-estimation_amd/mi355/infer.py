@@ -3,7 +3,7 @@ from a HIP graph.  Eager, one forward of the pose network is ~120 launches that 
 needs to run; replayed it is one graph launch."""
 import torch
 
-from . import nn as _nn
+from . import graph_capture_mode, nn as _nn
 
 
 class GraphedForward:
@@ -39,7 +39,7 @@ class GraphedForward:
             sx = x.clone()
             g = torch.cuda.CUDAGraph()
             torch.cuda.synchronize()
-            with torch.cuda.graph(g):
+            with torch.cuda.graph(g, capture_error_mode=graph_capture_mode()):
                 sy = self.model(sx)
             ent = self._graphs[key] = (g, sx, sy)
         g, sx, sy = ent
