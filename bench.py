@@ -290,10 +290,13 @@ def main():
     if not args.no_roofline and rank == 0:
         ms, launches, flops, abytes = ops.prof_read()
         log('roofline pass done')
-        # executed -> algorithmic FLOPs: the 3-channel stem runs padded to one 16-byte chunk (8 bf16 / 4 fp32 channels)
+        # executed -> algorithmic FLOPs of the 3-channel stem (K = 147): it runs as a 4x4 conv over the 2x2 space-to-depth image
+        # (K = 16 taps x 16 folded channels = 256) or, with odd extents / MI355_STEM_S2D=0, as the 7x7 conv over the image padded to
+        # one 16-byte chunk (K = 49 x 8 bf16 / 49 x 4 fp32 channels)
         cpad = 4 if args.dtype == 'f32' else 8
         stem_m = B * (S // 2) * (S // 2)
-        stem_excess = 2.0 * stem_m * 64 * 49 * (cpad - 3) * 4 * n_prof     # 2 fwd (A, shared B+C) + 2 wgrad (A, C) launches / iteration
+        stem_k = 256 if (getattr(model.backbone.conv1, '_s2d', False) and S % 2 == 0) else 49 * cpad
+        stem_excess = 2.0 * stem_m * 64 * (stem_k - 147) * 4 * n_prof      # 2 fwd (A, shared B+C) + 2 wgrad (A, C) launches / iteration
         algo = flops - stem_excess
         ach = algo / (ms * 1e-3) / 1e12
         peak = PEAK_TFLOPS[args.dtype]
