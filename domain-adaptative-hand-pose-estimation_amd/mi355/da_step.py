@@ -172,7 +172,7 @@ class DAStep:
 
     def _overlap_capturable(self):
         """Can the overlapped exchange be CAPTURED into the HIP graphs?  RCCL collectives are stream work and capture like kernels
-        (probed on this stack: scratch/rccl_graph_probe.py -- an async all-reduce on RCCL's stream inside torch.cuda.graph, replayed);
+        (probed on this stack: profiles/tools/rccl_graph_probe.py -- an async all-reduce on RCCL's stream inside torch.cuda.graph, replayed);
         gloo collectives are host work and cannot.  OPT-IN (MI355_DDP_GRAPH_OVERLAP=1): the default keeps the blocking exchange
         between the graphs -- on one xGMI node the two forms are expected within a few tenths of a millisecond of each other
         (DESIGN.md section 6), the captured form has only ever run in a one-rank group (no multi-GPU box in this build's reach), and
