@@ -1359,6 +1359,7 @@ static int dispatch_gather(GatherArgs& a, hipStream_t st) {
     const long t64 = cdiv(Mtot, 64L) * cdiv(a.Nout, 128);
     static const long splitk_min = getenv("MI355_SPLITK_MIN") ? atol(getenv("MI355_SPLITK_MIN")) : 128;
     static const long splitk_max = getenv("MI355_SPLITK_MAX") ? atol(getenv("MI355_SPLITK_MAX")) : 320;
+    static const long splitk_kmin = getenv("MI355_SPLITK_KMIN") ? atol(getenv("MI355_SPLITK_KMIN")) : 128;      // shortest K taken, in 16-byte chunks (128: the 1x1 convs with K = 1024 at 16x16 too, 30.88 / 30.81 -> 30.76 / 30.76 ms)
     bool kw3 = kw3_on && sizeof(T) == 2 && a.nphase == 1 && a.ph[0].ntaps == 9 && a.in_sx == 1 && a.in_sy == 1 && a.out_sx == 1 &&
                a.out_sy == 1 && a.ph[0].OWp == a.Wi && a.ph[0].OHp == a.Hi && a.Wo == a.Wi && a.Ho == a.Hi && a.Wi >= 8 &&
                a.Wi <= 128 && ilog2_exact(a.Wi) >= 0 && a.Nout > 64 && a.Ci % 64 == 0 && !a.bnb_partial;
@@ -1382,8 +1383,8 @@ static int dispatch_gather(GatherArgs& a, hipStream_t st) {
     //  two tiles in flight and counted vmcnt measured 33.5 us there: the per-CU fill rate, not latency, bounds these layers)
     // one 128 x 128 tile per CU or fewer and a long K: two K groups per workgroup (KG above) -- 3x3 256 -> 256 @16x16 and kin
     // fewer 128 x 128 tiles than CUs (the 8x8 maps: 128 of them would leave half the chip idle): 64-row tiles, two K groups each
-    else if (splitk_on >= 2 && dma_mode == 1 && t128 < 256 && t64 >= splitk_min && t64 <= 384 && kavg >= 256 && !a.bnb_partial) launch_gather<T, 64, 128, false, 2, 2, false, true, false, false, 2>(a, st);
-    else if (splitk_on && dma_mode == 1 && t128 >= splitk_min && t128 <= splitk_max && kavg >= 256 && !a.bnb_partial) launch_gather<T, 128, 128, false, 2, 2, false, true, false, false, 2>(a, st);
+    else if (splitk_on >= 2 && dma_mode == 1 && t128 < 256 && t64 >= splitk_min && t64 <= 384 && kavg >= splitk_kmin && !a.bnb_partial) launch_gather<T, 64, 128, false, 2, 2, false, true, false, false, 2>(a, st);
+    else if (splitk_on && dma_mode == 1 && t128 >= splitk_min && t128 <= splitk_max && kavg >= splitk_kmin && !a.bnb_partial) launch_gather<T, 128, 128, false, 2, 2, false, true, false, false, 2>(a, st);
     else if ((dma_mode == 2 && a.Nout > 64) || (dma_mode == 1 && ((t128 >= 512 && kavg >= 128) || (t128 >= 256 && kavg >= 256)))) launch_gather<T, 128, 128, false, 2, 2, false, true>(a, st);
     // short-K 1x1 convs at large M are all prologue / epilogue and HBM-bound: more, smaller blocks in flight win
     // (64->256 @64x64: 54.5 -> 47.0 us, 256->256: 79.6 -> 68.9 us)

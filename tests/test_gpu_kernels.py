@@ -66,6 +66,7 @@ CONV_CASES = [
     (64, 256, 64, 64, 256, 3, 2, 1),  # wgrad_kw2 at stage size + 4-phase strided dgrad + LDS-DMA ring forward (3x3 s2 256->256 @64->32, B=64)
     (64, 256, 16, 16, 256, 3, 1, 1),  # 256 tiles, K = 2304: the LDS-DMA ring on the mid-size layers (3x3 256->256 @16x16, B=64)
     (64, 512, 8, 8, 512, 3, 1, 1),    # 128 tiles of 128 x 128: 64-row tiles with two K groups per workgroup (3x3 512->512 @8x8, B=64)
+    (64, 1024, 16, 16, 256, 1, 1, 0),  # 256 tiles, K = 1024 in one tap: two K groups on a 1x1 conv (1024->256 @16x16, B=64)
 ]
 
 
