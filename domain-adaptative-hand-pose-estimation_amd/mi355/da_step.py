@@ -376,7 +376,7 @@ class DAStep:
         self.graphs = graphs          # capturing executes nothing: model / optimizer state is unchanged
         return self
 
-    def choose_launch_mode(self, batch, after=None, threshold=0.95):
+    def choose_launch_mode(self, batch, after=None, threshold=0.85):
         """Multi-rank runs.  With RCCL the overlapped gradient exchange is captured into the HIP graphs, so graph replay is chosen
         outright.  With a backend whose collectives cannot be captured (gloo rehearsals): eager launches keep the exchange
         overlapped with the backward, but only pay off while the host can feed the GPU.  Times one eager iteration on the host (enqueue) and on the GPU (enqueue + drain); if enqueueing
@@ -401,6 +401,8 @@ class DAStep:
             return 'graph' if forced == '1' else 'eager'
         if self._overlap_capturable():
             return 'graph'          # RCCL: the overlapped exchange is captured into the graphs -- replay loses nothing and cannot go host-bound
+        # (0.85, not ~1: one sample of the host's enqueue time on a node where eight ranks share the cores is an optimistic estimate, and
+        #  an eager run that goes host-bound loses more than the blocking exchange between the graphs costs)
         return 'graph' if self.host_gpu_ratio > threshold else 'eager'
 
     def _host_tick(self):
