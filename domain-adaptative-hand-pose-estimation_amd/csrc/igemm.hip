@@ -1360,9 +1360,10 @@ static int dispatch_gather(GatherArgs& a, hipStream_t st) {
     static const long splitk_min = getenv("MI355_SPLITK_MIN") ? atol(getenv("MI355_SPLITK_MIN")) : 128;
     static const long splitk_max = getenv("MI355_SPLITK_MAX") ? atol(getenv("MI355_SPLITK_MAX")) : 320;
     static const long splitk_kmin = getenv("MI355_SPLITK_KMIN") ? atol(getenv("MI355_SPLITK_KMIN")) : 128;      // shortest K taken, in 16-byte chunks (128: the 1x1 convs with K = 1024 at 16x16 too, 30.88 / 30.81 -> 30.76 / 30.76 ms)
+    static const int kw3_n64 = getenv("MI355_KW3_N64") ? atoi(getenv("MI355_KW3_N64")) : 1;      // A/B switch: the variant for 64 output channels
     bool kw3 = kw3_on && sizeof(T) == 2 && a.nphase == 1 && a.ph[0].ntaps == 9 && a.in_sx == 1 && a.in_sy == 1 && a.out_sx == 1 &&
                a.out_sy == 1 && a.ph[0].OWp == a.Wi && a.ph[0].OHp == a.Hi && a.Wo == a.Wi && a.Ho == a.Hi && a.Wi >= 8 &&
-               a.Wi <= 128 && ilog2_exact(a.Wi) >= 0 && a.Nout > 64 && a.Ci % 64 == 0 && !a.bnb_partial;
+               a.Wi <= 128 && ilog2_exact(a.Wi) >= 0 && (a.Nout > 64 || (kw3_n64 && a.Nout == 64)) && a.Ci % 64 == 0 && !a.bnb_partial;
     for (int g = 0; g < 3 && kw3; ++g) {
       const Tap* tp = a.taps + a.ph[0].tap0 + 3 * g;
       int seen = 0;
@@ -1371,7 +1372,10 @@ static int dispatch_gather(GatherArgs& a, hipStream_t st) {
     }
     if (kw3) a.lw = ilog2_exact(a.Wi);
     if (a.Nout <= 64) {
-      if (cdiv(Mtot, 128L) >= 512) launch_gather<T, 128, 64, false>(a, st); else launch_gather<T, 64, 64, false>(a, st);
+      // 3x3 64 -> 64 on the large maps (layer1 of the ResNets: 2048 tiles of 128 x 64): the shared-A-tile variant here too -- two
+      // thirds of what a 128 x 64 tile stages per tap is the A tile
+      if (kw3 && (cdiv(Mtot, 128L) >= 2048 || kw3_on == 2)) { if constexpr (sizeof(T) == 2) launch_gather<T, 128, 64, false, 2, 2, false, false, true>(a, st); }
+      else if (cdiv(Mtot, 128L) >= 512) launch_gather<T, 128, 64, false>(a, st); else launch_gather<T, 64, 64, false>(a, st);
     } else if (sizeof(T) == 2 && getenv("MI355_T256") && a.Nout % 256 == 0 && cdiv(Mtot, 256L) * (a.Nout / 256) >= 256) launch_gather<T, 256, 256, false, 2, 4>(a, st);
     // LDS-DMA ring for K-heavy layers (>= 16 K-tiles): +9..12 % on the 3x3 / 4x4 convs, but -15 % on short-K 1x1 convs
     // (2 blocks/CU instead of 3), so those keep the register-staged form.  MI355_DMA=0 disables, =2 forces (tests).
