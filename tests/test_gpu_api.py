@@ -434,3 +434,29 @@ def test_resnext_and_wide_resnet_backbones_train_through_the_pose_model(gpu, arc
         ye = model(x)
     ye = ye[0] if isinstance(ye, (tuple, list)) else ye
     assert tuple(ye.shape) == (2, 21, 32, 32) and bool(torch.isfinite(ye).all())
+
+
+@pytest.mark.parametrize('hw', [(32, 48), (31, 33)])
+def test_stem_layer_folded_and_padded_forms_match_torch(gpu, hw):
+    """mi355.nn.Conv2d(3, 64, 7, 2, 3): even extents take the folded 4x4 form (space-to-depth image), odd extents the 7x7 form over the
+    channel-padded image; both against F.conv2d in fp32 -- output and the (64, 3, 7, 7) weight gradient (overwrite, then accumulate)."""
+    import torch.nn.functional as F
+    from mi355 import nn as mnn
+    H, W = hw
+    conv = mnn.Conv2d(3, 64, 7, 2, 3, bias=False).to(gpu)
+    assert conv._s2d_ok(torch.empty(2, 3, H, W)) == (H % 2 == 0 and W % 2 == 0)
+    w = randn(111, 64, 3, 7, 7, scale=1.0 / np.sqrt(147))
+    with torch.no_grad():
+        conv.weight.copy_(w.to(gpu))
+    x = randn(112, 2, 3, H, W)
+    wr = w.clone().requires_grad_(True)
+    y_ref = F.conv2d(x, wr, None, stride=2, padding=3)
+    dy = randn(113, *y_ref.shape)
+    y_ref.backward(dy)
+    y = conv(x.to(gpu))
+    assert tuple(y.shape) == tuple(y_ref.shape)
+    assert float((y.detach().float().cpu() - y_ref.detach()).abs().max()) <= 1e-4 * float(y_ref.detach().abs().max())
+    y.backward(dy.to(gpu))
+    assert float((conv.weight.grad.cpu() - wr.grad).abs().max()) <= 1e-4 * float(wr.grad.abs().max())
+    conv(x.to(gpu)).backward(dy.to(gpu))
+    assert float((conv.weight.grad.cpu() - 2 * wr.grad).abs().max()) <= 2e-4 * float(wr.grad.abs().max())
