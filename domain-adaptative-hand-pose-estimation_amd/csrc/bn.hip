@@ -686,10 +686,10 @@ __global__ __launch_bounds__(256) void bn_relu_maxpool_kernel(const T* __restric
                                                                uint8_t* __restrict__ arg, int N, int H, int W, int C, int Ho, int Wo) {
   constexpr int CH = Chunk<T>::N;
   const int cpr = C / CH;
-  const long total = (long)N * Ho * Wo * cpr;
-  for (long id = (long)blockIdx.x * 256 + threadIdx.x; id < total; id += (long)gridDim.x * 256) {
-    const int ch = (int)(id % cpr); long r = id / cpr;
-    const int ox = (int)(r % Wo); r /= Wo; const int oy = (int)(r % Ho); const int n = (int)(r / Ho);
+  const unsigned total = (unsigned)N * Ho * Wo * cpr;            // (< 2^31: checked by the host; 32-bit index arithmetic -- 64-bit divisions cost more than the loads)
+  for (unsigned id = blockIdx.x * 256u + threadIdx.x; id < total; id += gridDim.x * 256u) {
+    const int ch = (int)(id % (unsigned)cpr); unsigned r = id / (unsigned)cpr;
+    const int ox = (int)(r % (unsigned)Wo); r /= (unsigned)Wo; const int oy = (int)(r % (unsigned)Ho); const int n = (int)(r / (unsigned)Ho);
     float sc[CH], sh[CH], best[CH]; int bi[CH]; bool first = true;
 #pragma unroll
     for (int e = 0; e < CH; ++e) { sc[e] = scale_shift[ch * CH + e]; sh[e] = scale_shift[C + ch * CH + e]; best[e] = -INFINITY; bi[e] = 0; }
@@ -712,8 +712,7 @@ __global__ __launch_bounds__(256) void bn_relu_maxpool_kernel(const T* __restric
     }
     const size_t o = (((size_t)n * Ho + oy) * Wo + ox) * C + (size_t)ch * CH;
     Chunk<T>::store(y + o, best);
-#pragma unroll
-    for (int e = 0; e < CH; ++e) arg[o + e] = (uint8_t)bi[e];
+    store_bytes<CH>(arg + o, bi);
   }
 }
 
@@ -835,6 +834,7 @@ extern "C" int mi355_bn_relu_maxpool_fwd_partials(const void* x, void* y_pool, u
   int CH; if (int e = bn_check(rows, C, dtype, &CH)) return e;
   if (stat_updates < 0 || stat_updates > 8) MI_FAIL(MI355_EINVAL, "bn_relu_maxpool_fwd_partials: stat_updates=%d", stat_updates);
   if (!partial || nslices < 1 || !scale_shift || !argidx || !y_pool) MI_FAIL(MI355_EINVAL, "bn_relu_maxpool_fwd_partials: null argument");
+  if (rows * (C / CH) >= (1L << 31)) MI_FAIL(MI355_EINVAL, "bn_relu_maxpool_fwd_partials: %ld chunks exceed the kernel's 32-bit index: split the batch", rows * (C / CH));
   hipStream_t st = as_stream(stream);
   static const int wide_min = getenv("MI355_BN_WIDE_FINALIZE") ? atoi(getenv("MI355_BN_WIDE_FINALIZE")) : 512;
   char lab[96];

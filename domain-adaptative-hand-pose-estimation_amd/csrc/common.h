@@ -64,6 +64,32 @@ template <> struct Chunk<bf16_t> {
   }
 };
 
+// CH consecutive bytes (CH = 8 or 4; the address is a multiple of CH) as ONE load / store: window-position bytes of the max-pool
+template <int CH> __device__ inline void load_bytes(const uint8_t* p, unsigned (&b)[CH]) {
+  if constexpr (CH == 8) {
+    const uint2 q = *reinterpret_cast<const uint2*>(p);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { b[e] = (q.x >> (8 * e)) & 0xffu; b[4 + e] = (q.y >> (8 * e)) & 0xffu; }
+  } else {
+    const unsigned q = *reinterpret_cast<const unsigned*>(p);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) b[e] = (q >> (8 * e)) & 0xffu;
+  }
+}
+template <int CH> __device__ inline void store_bytes(uint8_t* p, const int (&b)[CH]) {
+  if constexpr (CH == 8) {
+    uint2 q; q.x = 0u; q.y = 0u;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { q.x |= ((unsigned)b[e] & 0xffu) << (8 * e); q.y |= ((unsigned)b[4 + e] & 0xffu) << (8 * e); }
+    *reinterpret_cast<uint2*>(p) = q;
+  } else {
+    unsigned q = 0u;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) q |= ((unsigned)b[e] & 0xffu) << (8 * e);
+    *reinterpret_cast<unsigned*>(p) = q;
+  }
+}
+
 // ---- wave / block reductions ----------------------------------------------------------
 __device__ inline float wave_sum(float v) {
 #pragma unroll

@@ -7,10 +7,10 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* __restrict__ 
                                                            int N, int H, int W, int C, int Ho, int Wo) {
   constexpr int CH = Chunk<T>::N;
   const int cpr = C / CH;
-  const long total = (long)N * Ho * Wo * cpr;
-  for (long id = (long)blockIdx.x * 256 + threadIdx.x; id < total; id += (long)gridDim.x * 256) {
-    const int ch = (int)(id % cpr); long r = id / cpr;
-    const int ox = (int)(r % Wo); r /= Wo; const int oy = (int)(r % Ho); const int n = (int)(r / Ho);
+  const unsigned total = (unsigned)N * Ho * Wo * cpr;            // (< 2^31: checked by the host; 32-bit index arithmetic -- 64-bit divisions cost more than the loads)
+  for (unsigned id = blockIdx.x * 256u + threadIdx.x; id < total; id += gridDim.x * 256u) {
+    const int ch = (int)(id % (unsigned)cpr); unsigned r = id / (unsigned)cpr;
+    const int ox = (int)(r % (unsigned)Wo); r /= (unsigned)Wo; const int oy = (int)(r % (unsigned)Ho); const int n = (int)(r / (unsigned)Ho);
     float best[CH]; int bi[CH]; bool first = true;
 #pragma unroll
     for (int e = 0; e < CH; ++e) { best[e] = -INFINITY; bi[e] = 0; }
@@ -30,8 +30,7 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* __restrict__ 
     }
     const size_t o = (((size_t)n * Ho + oy) * Wo + ox) * C + (size_t)ch * CH;
     Chunk<T>::store(y + o, best);
-#pragma unroll
-    for (int e = 0; e < CH; ++e) arg[o + e] = (uint8_t)bi[e];
+    store_bytes<CH>(arg + o, bi);
   }
 }
 
@@ -40,24 +39,32 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T* __restrict__ 
                                                            int N, int H, int W, int C, int Ho, int Wo) {
   constexpr int CH = Chunk<T>::N;
   const int cpr = C / CH;
-  const long total = (long)N * H * W * cpr;
-  for (long id = (long)blockIdx.x * 256 + threadIdx.x; id < total; id += (long)gridDim.x * 256) {
-    const int ch = (int)(id % cpr); long r = id / cpr;
-    const int ix = (int)(r % W); r /= W; const int iy = (int)(r % H); const int n = (int)(r / H);
+  const unsigned total = (unsigned)N * H * W * cpr;              // (< 2^31: checked by the host)
+  for (unsigned id = blockIdx.x * 256u + threadIdx.x; id < total; id += gridDim.x * 256u) {
+    const int ch = (int)(id % (unsigned)cpr); unsigned r = id / (unsigned)cpr;
+    const int ix = (int)(r % (unsigned)W); r /= (unsigned)W; const int iy = (int)(r % (unsigned)H); const int n = (int)(r / (unsigned)H);
     float g[CH];
 #pragma unroll
     for (int e = 0; e < CH; ++e) g[e] = 0.f;
-    for (int kh = 0; kh < 3; ++kh) {
-      const int ty = iy + 1 - kh; if (ty < 0 || (ty & 1)) continue; const int oy = ty >> 1; if (oy >= Ho) continue;
-      for (int kw = 0; kw < 3; ++kw) {
-        const int tx = ix + 1 - kw; if (tx < 0 || (tx & 1)) continue; const int ox = tx >> 1; if (ox >= Wo) continue;
-        const size_t o = (((size_t)n * Ho + oy) * Wo + ox) * C + (size_t)ch * CH;
-        float d[CH]; Chunk<T>::load(dy + o, d);
-        const int code = kh * 3 + kw;
+    // Input row iy lies in window row oy0 = iy / 2 (at kernel row kh0 = iy - 2 oy0 + 1 = 1 or 2) and, when iy is odd, also in
+    // oy0 + 1 (kh = 0); columns alike: at most 2 x 2 windows, visited as straight-line predicated code (the 3 x 3 loop with its
+    // parity tests diverged inside every wave: 78 us for 185 MB)
+    const int oy0 = iy >> 1, ox0 = ix >> 1;
+    const int khs[2] = {iy - 2 * oy0 + 1, 0}, kws[2] = {ix - 2 * ox0 + 1, 0};
+    const bool vy[2] = {oy0 < Ho, (iy & 1) && oy0 + 1 < Ho}, vx[2] = {ox0 < Wo, (ix & 1) && ox0 + 1 < Wo};
 #pragma unroll
-        for (int e = 0; e < CH; ++e) if (arg[o + e] == code) g[e] += d[e];
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        if (vy[a] && vx[b]) {
+          const size_t o = (((size_t)n * Ho + oy0 + a) * Wo + ox0 + b) * C + (size_t)ch * CH;
+          float d[CH]; Chunk<T>::load(dy + o, d);
+          unsigned ab[CH]; load_bytes<CH>(arg + o, ab);
+          const unsigned code = (unsigned)(khs[a] * 3 + kws[b]);
+#pragma unroll
+          for (int e = 0; e < CH; ++e) if (ab[e] == code) g[e] += d[e];
+        }
       }
-    }
     Chunk<T>::store(dx + (((size_t)n * H + iy) * W + ix) * C + (size_t)ch * CH, g);
   }
 }
@@ -65,6 +72,7 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T* __restrict__ 
 extern "C" int mi355_maxpool_fwd(const void* x, void* y, uint8_t* argidx, int N, int H, int W, int C, int dtype, void* stream) {
   const int CH = dtype == MI355_BF16 ? 8 : 4;
   if (C % CH || N < 1 || !argidx) MI_FAIL(MI355_EINVAL, "maxpool_fwd: bad args (C=%d)", C);
+  if ((long)N * H * W * (C / CH) >= (1L << 31)) MI_FAIL(MI355_EINVAL, "maxpool_fwd: %ld chunks exceed the kernel's 32-bit index: split the batch", (long)N * H * W * (C / CH));
   const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
   long total = (long)N * Ho * Wo * (C / CH);
   int grid = (int)((total + 255) / 256); if (grid > 8192) grid = 8192;
@@ -77,6 +85,7 @@ extern "C" int mi355_maxpool_fwd(const void* x, void* y, uint8_t* argidx, int N,
 extern "C" int mi355_maxpool_bwd(const void* dy, const uint8_t* argidx, void* dx, int N, int H, int W, int C, int dtype, void* stream) {
   const int CH = dtype == MI355_BF16 ? 8 : 4;
   if (C % CH || N < 1 || !argidx) MI_FAIL(MI355_EINVAL, "maxpool_bwd: bad args (C=%d)", C);
+  if ((long)N * H * W * (C / CH) >= (1L << 31)) MI_FAIL(MI355_EINVAL, "maxpool_bwd: %ld chunks exceed the kernel's 32-bit index: split the batch", (long)N * H * W * (C / CH));
   const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
   long total = (long)N * H * W * (C / CH);
   int grid = (int)((total + 255) / 256); if (grid > 8192) grid = 8192;
