@@ -828,6 +828,142 @@ __global__ __launch_bounds__(256, 3) void wgrad_group_kernel(const WgradGroupArg
   wgrad_gemm_body<T>(g.p[i], (int)blockIdx.x - g.bstart[i], g.bstart[i + 1] - g.bstart[i], smem);
 }
 
+// 256 x 256 output tiles for the grouped 1x1 weight gradients with >= 256 channels on both sides (bf16; layer3 / layer4 of the
+// ResNets).  By counters the 128 x 128 form fetches 2 - 7x its operands from beyond L2 (the sibling tiles of a pixel range do not find
+// each other's lines in the 4-MB L2s: the layer4 group moved 0.94 GB through L1 for 0.15 GB of x + dy), i.e. those launches are
+// bound by L2-miss bandwidth.  Here a block of 8 waves owns 256 output channels x 256 input channels: per 64-pixel step four
+// [64][128] images (two DY halves, two X halves; same tr16 swizzle and fragment reads as the 128 x 128 body) = 64 KB for 256 MFMAs
+// -- half the bytes per MFMA -- travel global -> LDS by LDS-DMA into a two-stage ring (the swizzle applied on the per-lane source
+// address, out-of-range lanes deliver zeros; one barrier per step, no staging registers: a register-staged form of this tile, one
+// block per CU with two barriers per step, measured SLOWER than the 128 x 128 kernel: 265 vs 223 us on the layer3 group), and every
+// wave multiplies a 128 x 64 sub-tile (128 accumulators).  1x1 convs only (stride 1 or 2): a column is an input channel.
+#define WG256_IMG (64 * 256)
+template <int OFF> __device__ __forceinline__ bf16x4_t wg256_tr(unsigned a) {
+  bf16x4_t v; asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(a), "n"(OFF)); return v;
+}
+// one 16-pixel sub-step of a wave's 128 x 64 sub-tile: 12 transposed fragment reads (asm), one counted wait that names them, 8 MFMAs
+template <int OFF> __device__ __forceinline__ void wg256_step(unsigned st, const int (&trA)[4][2], const int (&trB)[2][2], f32x16_t (&acc)[4][2]) {
+  bf16x4_t a0[4], a1[4], b0[2], b1[2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { a0[i] = wg256_tr<OFF>(st + (unsigned)trA[i][0]); a1[i] = wg256_tr<OFF>(st + (unsigned)trA[i][1]); }
+#pragma unroll
+  for (int j = 0; j < 2; ++j) { b0[j] = wg256_tr<OFF>(st + (unsigned)trB[j][0]); b1[j] = wg256_tr<OFF>(st + (unsigned)trB[j][1]); }
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a0[0]), "+v"(a0[1]), "+v"(a0[2]), "+v"(a0[3]), "+v"(a1[0]), "+v"(a1[1]), "+v"(a1[2]), "+v"(a1[3]),
+               "+v"(b0[0]), "+v"(b0[1]), "+v"(b1[0]), "+v"(b1[1]));
+  bf16x8_t a[4], b[2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) a[i] = __builtin_shufflevector(a0[i], a1[i], 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+  for (int j = 0; j < 2; ++j) b[j] = __builtin_shufflevector(b0[j], b1[j], 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+}
+#define WG256_SMEM (2 * 4 * WG256_IMG + 2 * 64 * 4)
+__device__ __forceinline__ void wgrad_gemm256_body(const WgradArgs& p, const int bid, const int nblk, char* smem) {
+  constexpr int BKM = 64, IMG = WG256_IMG, STAGE = 4 * IMG;
+  int* rowpix = reinterpret_cast<int*>(smem + 2 * STAGE);      // [2][BKM]: input pixel index of every reduction row
+  const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int ntile = p.nto * p.nti;                   // (in 256 x 256 tiles)
+  const int lid = xcd_remap(bid, nblk);
+  const int split = lid / ntile, tile = lid - split * ntile;
+  const int o0 = (tile / p.nti) * 256, c0 = (tile % p.nti) * 256;
+  const int wo = wave >> 2, wc = wave & 3;           // multiply: DY image wo (128 output channels), X image wc >> 1, columns (wc & 1) * 64 ..
+  const __amdgpu_buffer_rsrc_t rsX = make_rsrc(p.X, p.x_bytes), rsY = make_rsrc(p.DY, p.dy_bytes);
+  const int mbeg = split * p.rows_per_split;
+  const int mend = min(p.M, mbeg + p.rows_per_split);
+  // staging: wave w fills image w >> 1 (0, 1: DY halves, 2, 3: X halves), row groups (w & 1) * 8 + j, j = 0 .. 7, of four rows each;
+  // lane -> row (lane >> 4) of the group, physical chunk lane & 15, which holds the logical chunk pc ^ (((r & 3) << 2) | ((r >> 2) & 3))
+  const int img = wave >> 1, half = img & 1;
+  const bool isx = img >= 2;
+  const int rsub = lane >> 4, pc = lane & 15;
+  int colb[4];                                       // byte offset of this lane's column for row groups with (group & 3) == q
+#pragma unroll
+  for (int q = 0; q < 4; ++q) colb[q] = ((isx ? c0 : o0) + half * 128 + ((pc ^ ((rsub << 2) | q)) << 3)) * 2;
+  const int ld2 = (isx ? p.Ci : p.Co) * 2;           // row pitch in bytes
+  auto decode_rows = [&](int mt0, int buf) {
+    if (t < BKM) {
+      const unsigned m = (unsigned)(mt0 + t);
+      unsigned r = fd_div(m, p.dWo); int ox = (int)(m - r * p.Wo);
+      unsigned n = fd_div(r, p.dHo); int oy = (int)(r - n * p.Ho);
+      rowpix[buf * BKM + t] = ((int)n * p.Hi + oy * p.stride) * p.Wi + ox * p.stride;
+    }
+  };
+  auto dma_tile = [&](int mt0, int stage, int buf) {
+    (void)mt0; (void)stage; (void)buf;
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef __attribute__((address_space(3))) void* ldsp;
+    char* dst = smem + stage * STAGE + img * IMG + (wave & 1) * 8 * 1024;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int r = ((wave & 1) * 8 + j) * 4 + rsub, m = mt0 + r;
+      const int row = isx ? rowpix[buf * BKM + r] : m;
+      const int off = m < mend ? row * ld2 + colb[j & 3] : OOB_OFF;
+      if (isx) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, (ldsp)(dst + j * 1024), 16, off, 0, 0, 0);
+      else __builtin_amdgcn_raw_ptr_buffer_load_lds(rsY, (ldsp)(dst + j * 1024), 16, off, 0, 0, 0);
+    }
+#endif
+  };
+  f32x16_t acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  const int r31 = lane & 31, hi = lane >> 5;
+  const int tg = lane >> 4, tq = (lane & 15) >> 2, tp = lane & 3;      // tr16 lane roles (as in wgrad_gemm_body)
+  const int wn0 = (wc & 1) * 64;
+  int trA[4][2], trB[2][2];
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int row = 8 * (tg >> 1) + tq + 4 * u;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) trA[i][u] = wo * IMG + swz256(row, (i * 32) / 8 + 2 * (tg & 1) + (tp >> 1)) + 8 * (tp & 1);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) trB[j][u] = (2 + (wc >> 1)) * IMG + swz256(row, (wn0 + j * 32) / 8 + 2 * (tg & 1) + (tp >> 1)) + 8 * (tp & 1);
+  }
+  typedef __attribute__((address_space(3))) char* lds_cptr256;
+  const unsigned smem_lds = (unsigned)(uintptr_t)(lds_cptr256)smem;
+  decode_rows(mbeg, 0);
+  decode_rows(mbeg + BKM, 1);
+  __syncthreads();
+  if (mbeg < mend) dma_tile(mbeg, 0, 0);
+  int it = 0;
+  for (int mt0 = mbeg; mt0 < mend; mt0 += BKM, ++it) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's pieces of tile `it` have landed
+#endif
+    __syncthreads();                                         // everyone's have; stage (it + 1) & 1 is no longer being read
+    if (mt0 + BKM < mend) dma_tile(mt0 + BKM, (it + 1) & 1, (it + 1) & 1);
+    decode_rows(mt0 + 2 * BKM, it & 1);                      // (row buffer it & 1 was consumed by the DMA issued one trip ago)
+    // The fragment reads are inline asm: hipcc guards every LDS read it can see behind an LDS-DMA with `s_waitcnt vmcnt(0)`, i.e. it
+    // would wait for the tile issued a few lines up before multiplying this one (seen in the disassembly of the builtin form).
+    const unsigned st = smem_lds + (unsigned)((it & 1) * STAGE);
+    __builtin_amdgcn_s_setprio(1);
+    wg256_step<0>(st, trA, trB, acc); wg256_step<4096>(st, trA, trB, acc); wg256_step<8192>(st, trA, trB, acc); wg256_step<12288>(st, trA, trB, acc);
+    __builtin_amdgcn_s_setprio(0);
+  }
+  float* out = p.out + (size_t)split * p.slab_stride;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int o = o0 + wo * 128 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+        const int c = c0 + (wc >> 1) * 128 + wn0 + j * 32 + r31;
+        if (o < p.Co && c < p.ldw) out[(size_t)o * p.ldw + c] = acc[i][j][r];
+      }
+}
+__global__ __launch_bounds__(512, 1) void wgrad_group256_kernel(const WgradGroupArgs g) {
+  extern __shared__ __attribute__((aligned(16))) char smem256[];
+  int i = 0;
+  while (i + 1 < g.n && (int)blockIdx.x >= g.bstart[i + 1]) ++i;
+  wgrad_gemm256_body(g.p[i], (int)blockIdx.x - g.bstart[i], g.bstart[i + 1] - g.bstart[i], smem256);
+}
+
 // grouped fixed-order slab reduction: out_i (=|+=) sum over the S_i slabs of problem i, one float4 column per thread
 struct SlabItem { const float* slabs; float* out; long n4, stride; int S, accumulate; };
 struct SlabGroupArgs { SlabItem it[WG_MAX]; int bstart[WG_MAX + 1]; int n; };
@@ -1792,18 +1928,42 @@ extern "C" int mi355_conv_wgrad(const mi355_conv_desc* d, const void* x, const v
 static bool group_eligible(const mi355_conv_desc* d, const WgradPlan& w) {
   return !w.kw2 && !w.kw3 && (long)w.nto * w.nti < 384;
 }
+// ... and of those, the ones the 256 x 256-tile kernel takes (wgrad_group256_kernel): bf16, whole 256-wide tiles both ways
+static bool group256_eligible(const mi355_conv_desc* d, const WgradPlan& w) {
+  static const bool on = !(getenv("MI355_WGRAD_GROUP256") && atoi(getenv("MI355_WGRAD_GROUP256")) == 0);      // A/B switch
+  return on && d->dtype == MI355_BF16 && d->kh == 1 && d->kw == 1 && d->pad == 0 && d->Co % 256 == 0 && d->Ci % 256 == 0;
+}
 struct GroupPlan { int S, rps; size_t ws_off; };
-static long group_plan(const mi355_wgrad_item* items, const int* idx, int n, GroupPlan* gp, size_t* ws_bytes) {
+// tile: 128 (wgrad_group_kernel) or 256 (wgrad_group256_kernel)
+static long group_plan(const mi355_wgrad_item* items, const int* idx, int n, GroupPlan* gp, size_t* ws_bytes, int tile = 128) {
   // equal work per block: block-steps W = sum tiles_i * ksteps_i; aim at 3 blocks per CU, never fewer than 16 K-steps per block
+  // (256-wide tiles: one 8-wave block per CU)
   double W = 0;
   for (int k = 0; k < n; ++k) {
     const mi355_conv_desc* d = &items[idx[k]].d; WgradPlan w = plan_wgrad(d);
     const int bkm = d->dtype == MI355_BF16 ? 64 : 32;
-    W += (double)w.nto * w.nti * (((long)d->N * d->Ho * d->Wo + bkm - 1) / bkm);
+    const long tiles = tile == 256 ? (long)(d->Co / 256) * (w.ldw / 256) : (long)w.nto * w.nti;
+    W += (double)tiles * (((long)d->N * d->Ho * d->Wo + bkm - 1) / bkm);
   }
   static const int group_blocks = getenv("MI355_WG_GROUP_BLOCKS") ? atoi(getenv("MI355_WG_GROUP_BLOCKS")) : 512;     // (768 -> 512: -0.09 ms / iteration, three same-box pairs)
-  long per = (long)(W / group_blocks) + 1; if (per < 16) per = 16;
+  static const int group256_blocks = getenv("MI355_WG_GROUP256_BLOCKS") ? atoi(getenv("MI355_WG_GROUP256_BLOCKS")) : 256;
+  long per = (long)(W / (tile == 256 ? group256_blocks : group_blocks)) + 1; if (per < 16) per = 16;
   long blocks = 0; size_t off = 0;
+  // 256-wide tiles run one block per CU: a grid of 294 blocks on 256 CUs would take two rounds, the second nearly empty -- lengthen
+  // the blocks until the group fits the target (rounding the split counts up is what overshoots it)
+  for (int trial = 0; tile == 256 && trial < 64; ++trial) {
+    long b = 0;
+    for (int k = 0; k < n; ++k) {
+      const mi355_conv_desc* d = &items[idx[k]].d; WgradPlan w = plan_wgrad(d);
+      const long M = (long)d->N * d->Ho * d->Wo, ksteps = (M + 63) / 64;
+      long S = (ksteps + per - 1) / per; if (S < 1) S = 1;
+      long rps = (M + S - 1) / S; rps = ((rps + 63) / 64) * 64;
+      S = (M + rps - 1) / rps;
+      b += (long)(d->Co / 256) * (w.ldw / 256) * S;
+    }
+    if (b <= group256_blocks) break;
+    per += per / 16 + 1;
+  }
   for (int k = 0; k < n; ++k) {
     const mi355_wgrad_item& it = items[idx[k]]; const mi355_conv_desc* d = &it.d; WgradPlan w = plan_wgrad(d);
     const int bkm = d->dtype == MI355_BF16 ? 64 : 32;
@@ -1813,7 +1973,7 @@ static long group_plan(const mi355_wgrad_item* items, const int* idx, int n, Gro
     S = (M + rps - 1) / rps;
     gp[k].S = (int)S; gp[k].rps = (int)rps; gp[k].ws_off = off;
     if (S > 1 || it.accumulate) off += (size_t)S * d->Co * w.ldw * sizeof(float);
-    blocks += (long)w.nto * w.nti * S;
+    blocks += (tile == 256 ? (long)(d->Co / 256) * (w.ldw / 256) : (long)w.nto * w.nti) * S;
   }
   if (ws_bytes) *ws_bytes = off;
   return blocks;
@@ -1903,19 +2063,24 @@ static int launch_wgrad_kw_group(const mi355_wgrad_item* items, const int* idx, 
 // their order: whatever is pending goes first.
 template <typename F>
 static int walk_wgrad_groups(const mi355_wgrad_item* items, int n, F&& fn) {
-  int gi[WG_MAX], ki[WGK_MAX]; int gm = 0, km = 0;
+  int gi[WG_MAX], ki[WGK_MAX], bi[WG_MAX]; int gm = 0, km = 0, bm = 0;
   auto flush_g = [&]() -> int { if (!gm) return 0; int e = fn(1, gi, gm); gm = 0; return e; };
   auto flush_k = [&]() -> int { if (!km) return 0; int e = fn(2, ki, km); km = 0; return e; };
+  auto flush_b = [&]() -> int { if (!bm) return 0; int e = fn(3, bi, bm); bm = 0; return e; };
   for (int i = 0; i < n; ++i) {
     const mi355_wgrad_item& it = items[i];
     WgradPlan w = plan_wgrad(&it.d);
     bool shares = false;
     for (int k = 0; k < gm; ++k) shares = shares || items[gi[k]].dw == it.dw;
     for (int k = 0; k < km; ++k) shares = shares || items[ki[k]].dw == it.dw;
-    if (shares) { if (int e = flush_g()) return e; if (int e = flush_k()) return e; }
+    for (int k = 0; k < bm; ++k) shares = shares || items[bi[k]].dw == it.dw;
+    if (shares) { if (int e = flush_g()) return e; if (int e = flush_k()) return e; if (int e = flush_b()) return e; }
     if (kw_group_eligible(&it.d, w)) {
       if (km && (km == WGK_MAX || plan_wgrad(&items[ki[0]].d).mt != w.mt)) { if (int e = flush_k()) return e; }
       ki[km++] = i;
+    } else if (group_eligible(&it.d, w) && group256_eligible(&it.d, w)) {
+      if (bm == WG_MAX) { if (int e = flush_b()) return e; }
+      bi[bm++] = i;
     } else if (group_eligible(&it.d, w)) {
       if (gm && (gm == WG_MAX || items[gi[0]].d.dtype != it.d.dtype)) { if (int e = flush_g()) return e; }
       gi[gm++] = i;
@@ -1925,6 +2090,7 @@ static int walk_wgrad_groups(const mi355_wgrad_item* items, int n, F&& fn) {
     }
   }
   if (int e = flush_g()) return e;
+  if (int e = flush_b()) return e;
   return flush_k();
 }
 extern "C" size_t mi355_conv_wgrad_grouped_workspace(const mi355_wgrad_item* items, int n) {
@@ -1934,15 +2100,16 @@ extern "C" size_t mi355_conv_wgrad_grouped_workspace(const mi355_wgrad_item* ite
     size_t b = 0;
     if (kind == 0) b = mi355_conv_wgrad_workspace(&items[idx[0]].d);
     else if (kind == 1) { GroupPlan gp[WG_MAX]; group_plan(items, idx, m, gp, &b); }
+    else if (kind == 3) { GroupPlan gp[WG_MAX]; group_plan(items, idx, m, gp, &b, 256); }
     else { GroupPlan gp[WGK_MAX]; kw_group_plan(items, idx, m, gp, &b); }
     if (b > need) need = b;
     return 0;
   });
   return need;
 }
-static int launch_wgrad_group(const mi355_wgrad_item* items, const int* idx, int n, void* ws, size_t ws_bytes, hipStream_t st) {
+static int launch_wgrad_group(const mi355_wgrad_item* items, const int* idx, int n, void* ws, size_t ws_bytes, hipStream_t st, int tile = 128) {
   GroupPlan gp[WG_MAX]; size_t need = 0;
-  group_plan(items, idx, n, gp, &need);
+  group_plan(items, idx, n, gp, &need, tile);
   if (need && (!ws || ws_bytes < need)) MI_FAIL(MI355_EWORKSPACE, "wgrad group workspace %zu < %zu", ws_bytes, need);
   WgradGroupArgs g; memset(&g, 0, sizeof(g));
   SlabGroupArgs sg; memset(&sg, 0, sizeof(sg));
@@ -1962,10 +2129,11 @@ static int launch_wgrad_group(const mi355_wgrad_item* items, const int* idx, int
     a.kw = d->kw; a.stride = d->stride; a.pad = d->pad; a.cshift = cshift;
     a.M = d->N * d->Ho * d->Wo; a.rows_per_split = gp[k].rps; a.ldw = w.ldw;
     a.slab_stride = (long)d->Co * w.ldw; a.nto = w.nto; a.nti = w.nti;
+    if (tile == 256) { a.nto = d->Co / 256; a.nti = w.ldw / 256; }
     a.dWo = make_fastdiv(d->Wo); a.dHo = make_fastdiv(d->Ho);
     const long esz = d->dtype == MI355_BF16 ? 2 : 4;
     a.x_bytes = (unsigned)((long)d->N * d->Hi * d->Wi * d->Ci * esz); a.dy_bytes = (unsigned)((long)a.M * d->Co * esz);
-    g.bstart[k] = nb; nb += w.nto * w.nti * gp[k].S;
+    g.bstart[k] = nb; nb += a.nto * a.nti * gp[k].S;
     if (!direct) {
       SlabItem& q = sg.it[sg.n];
       q.slabs = a.out; q.out = it.dw; q.n4 = a.slab_stride / 4; q.stride = a.slab_stride; q.S = gp[k].S; q.accumulate = it.accumulate;
@@ -1978,10 +2146,15 @@ static int launch_wgrad_group(const mi355_wgrad_item* items, const int* idx, int
     for (int k = 0; k < n; ++k) { const WgradArgs& a = g.p[k]; flops += 2.0 * a.M * (double)a.Co * a.ldw; bytes += (double)a.x_bytes + a.dy_bytes + 4.0 * a.Co * a.ldw; }
     if (prof_on()) {
       const mi355_conv_desc* d0 = &items[idx[0]].d;
-      prof_set_tag("wgrad_group x%d blocks%d first k%ds%d %d>%d @%dx%d", n, nb, d0->kh, d0->stride, d0->Ci, d0->Co, d0->Hi, d0->Wi);
+      prof_set_tag("wgrad_group%s x%d blocks%d first k%ds%d %d>%d @%dx%d", tile == 256 ? "256" : "", n, nb, d0->kh, d0->stride, d0->Ci, d0->Co, d0->Hi, d0->Wi);
     }
     ProfScope ps(st, flops, bytes);
-    if (items[idx[0]].d.dtype == MI355_BF16) hipLaunchKernelGGL(wgrad_group_kernel<bf16_t>, dim3(nb), dim3(256), 0, st, g);
+    if (tile == 256) {
+      static bool attr_set = false;
+      if (!attr_set) { (void)hipFuncSetAttribute((const void*)wgrad_group256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, WG256_SMEM); attr_set = true; }
+      hipLaunchKernelGGL(wgrad_group256_kernel, dim3(nb), dim3(512), WG256_SMEM, st, g);
+    }
+    else if (items[idx[0]].d.dtype == MI355_BF16) hipLaunchKernelGGL(wgrad_group_kernel<bf16_t>, dim3(nb), dim3(256), 0, st, g);
     else hipLaunchKernelGGL(wgrad_group_kernel<float>, dim3(nb), dim3(256), 0, st, g);
     MI_CHECK_LAUNCH("wgrad_group");
   }
@@ -2004,6 +2177,7 @@ extern "C" int mi355_conv_wgrad_grouped(const mi355_wgrad_item* items, int n, vo
   return walk_wgrad_groups(items, n, [&](int kind, const int* idx, int m) -> int {
     if (kind == 0) { const mi355_wgrad_item& it = items[idx[0]]; return mi355_conv_wgrad(&it.d, it.x, it.dy, it.dw, it.accumulate, ws, ws_bytes, stream); }
     if (kind == 1) return launch_wgrad_group(items, idx, m, ws, ws_bytes, st);
+    if (kind == 3) return launch_wgrad_group(items, idx, m, ws, ws_bytes, st, 256);
     return launch_wgrad_kw_group(items, idx, m, ws, ws_bytes, st);
   });
 }

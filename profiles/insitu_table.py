@@ -19,13 +19,13 @@ MFMA, HBM = 1.75e15, 6.3e12
 # kernel-name pattern of each logged launch, by label prefix
 PAT = [('fwd8', 'gather_fp8_kernel'), ('dgrad8', 'gather_fp8_kernel'), ('fwd', ('gather_gemm_kernel', 'pgemm_kernel')),
        ('dgrad', ('gather_gemm_kernel', 'pgemm_kernel')), ('hm1x1', 'gather_gemm_kernel'), ('wgrad_kw_group', 'wgrad_kw_group_kernel'),
-       ('wgrad_kw2', 'wgrad_kw2_kernel'), ('wgrad_kw', 'wgrad_kw_kernel'), ('wgrad_group', 'wgrad_group_kernel'),
+       ('wgrad_kw2', 'wgrad_kw2_kernel'), ('wgrad_kw', 'wgrad_kw_kernel'), ('wgrad_group256', 'wgrad_group256_kernel'), ('wgrad_group', 'wgrad_group_kernel'),
        ('wgrad8', 'wgrad_kw'), ('wgrad', 'wgrad_gemm_kernel'),
        ('bn_stats', 'bn_stats_kernel'), ('bn_finalize', 'bn_finalize'), ('bn_apply', 'bn_apply_kernel'), ('bn_relu_maxpool', 'bn_relu_maxpool_kernel'),
        ('bn_bwd_res', 'bn_bwd_resident_kernel'), ('bn_bwd_reduce', 'bn_bwd_reduce_kernel'), ('bn_bwd_finalize', 'bn_bwd_finalize_kernel'),
        ('bn_bwd_apply', 'bn_bwd_apply_kernel'), ('slab_reduce_group', 'slab_reduce_group_kernel'), ('slab_reduce', 'slab_reduce_kernel')]
 FAMILY_KERNELS = {0: ('gather_gemm_kernel', 'gather_fp8_kernel', 'pgemm_kernel', 'wgrad_gemm_kernel', 'wgrad_kw_kernel', 'wgrad_kw2_kernel',
-                      'wgrad_group_kernel', 'wgrad_kw_group_kernel', 'wgrad_kw8_kernel', 'wgrad_kw28_kernel'),
+                      'wgrad_group_kernel', 'wgrad_group256_kernel', 'wgrad_kw_group_kernel', 'wgrad_kw8_kernel', 'wgrad_kw28_kernel'),
                   1: ('bn_stats_kernel', 'bn_finalize_kernel', 'bn_finalize_wide_kernel', 'bn_apply_kernel', 'bn_relu_maxpool_kernel',
                       'bn_bwd_resident_kernel', 'bn_bwd_reduce_kernel', 'bn_bwd_finalize_kernel', 'bn_bwd_apply_kernel'),
                   2: ('slab_reduce_kernel', 'slab_reduce_group_kernel')}

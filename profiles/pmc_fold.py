@@ -18,7 +18,7 @@ import sys
 
 FAMILIES = [            # first match wins
     ('conv_mfma', ('gather_gemm_kernel', 'wgrad_gemm_kernel', 'wgrad_kw_kernel', 'wgrad_kw2_kernel', 'wgrad_kw_group_kernel', 'gather_fp8_kernel', 'pgemm_kernel',
-                   'wgrad_group_kernel', 'wgrad_kw8_kernel', 'wgrad_kw28_kernel')),
+                   'wgrad_group_kernel', 'wgrad_group256_kernel', 'wgrad_kw8_kernel', 'wgrad_kw28_kernel')),
     ('slab_reduce', ('slab_reduce_kernel', 'slab_reduce_group_kernel')),
     ('bn_fwd', ('bn_stats_kernel', 'bn_apply_kernel', 'bn_finalize_kernel', 'bn_finalize_wide_kernel', 'bn_relu_maxpool_kernel')),
     ('bn_bwd', ('bn_bwd_resident_kernel', 'bn_bwd_reduce_kernel', 'bn_bwd_apply_kernel', 'bn_bwd_finalize_kernel')),

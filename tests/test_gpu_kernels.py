@@ -1060,6 +1060,32 @@ def test_grouped_weight_gradients_of_a_resnet_stage_at_full_size(gpu):
         assert float((dw - ref).abs().max()) <= 2e-3 * float(ref.abs().max()), (i, shapes[i])
 
 
+def test_grouped_weight_gradients_on_256_wide_tiles(gpu):
+    """wgrad_group256_kernel (256 x 256 output tiles, 8 waves; the 1x1 convs with >= 256 channels on both sides): layer4's shapes at
+    the benchmark's size -- 512 <-> 2048 @8x8, the strided 1024 -> 2048 down-sample -- and a head's 256 -> 256 @16x16, some items
+    accumulating onto a prefilled gradient, mixed with an item the kernel does not take (128 -> 512: 128-wide columns) -- every
+    problem against torch's fp32 weight gradient on the same bf16-rounded operands."""
+    ops = _ops()
+    tdt = torch.bfloat16
+    shapes = [(64, 8, 8, 2048, 512, 1, 1, 0, False), (64, 8, 8, 512, 2048, 1, 1, 0, True), (64, 16, 16, 1024, 2048, 1, 2, 0, False),
+              (64, 32, 32, 128, 512, 1, 1, 0, False), (64, 16, 16, 256, 256, 1, 1, 0, True), (3, 9, 7, 256, 512, 1, 1, 0, False)]
+    items, refs = [], []
+    for i, (N, H, W, Ci, Co, k, s, p, acc) in enumerate(shapes):
+        d = ops.make_desc(N, H, W, Ci, Co, k, k, s, p, tdt)
+        x = ops.nhwc_empty(N, Ci, H, W, tdt, gpu).normal_()
+        dy = ops.nhwc_empty(N, Co, d.Ho, d.Wo, tdt, gpu).normal_()
+        xs = x[:, :, ::s, ::s].permute(0, 2, 3, 1).reshape(-1, Ci).float()
+        ref = (dy.permute(0, 2, 3, 1).reshape(-1, Co).float().t() @ xs).reshape(-1)
+        dw = torch.full((Co * Ci,), 0.5 if acc else float('nan'), device=gpu)
+        refs.append(ref + 0.5 if acc else ref)
+        items.append((d, x, dy, dw, acc))
+    ops.conv_wgrad_grouped(items)
+    torch.cuda.synchronize()
+    for i, ((d, x, dy, dw, acc), ref) in enumerate(zip(items, refs)):
+        assert torch.isfinite(dw).all(), i
+        assert float((dw - ref).abs().max()) <= 2e-3 * float(ref.abs().max()), (i, shapes[i])
+
+
 def test_grouped_3x3_weight_gradients_of_resnet_stages_at_full_size(gpu):
     """The 3x3 / stride-1 weight gradients of a ResNet stage in one wgrad_kw_group launch (B=64, bf16): layer3's six 256 -> 256
     @16x16, layer1's 64 -> 64 @64x64 (one output-channel tile: its own group), layer4's 512 -> 512 @8x8, layer2's 128 -> 128 @32x32,
