@@ -2057,7 +2057,7 @@ static int launch_wgrad_kw_group(const mi355_wgrad_item* items, const int* idx, 
   return MI355_OK;
 }
 // The launches mi355_conv_wgrad_grouped makes of `items`, in order, handed to `fn(kind, idx, m)`: kind 0 = one item through
-// mi355_conv_wgrad, 1 = a group of the generic kernel, 2 = a group of the 3x3 / stride-1 kernel.  One walk for the launcher and
+// mi355_conv_wgrad, 1 = a group of the generic kernel, 2 = a group of the 3x3 / stride-1 kernel, 3 = a group of the 256 x 256-tile kernel.  One walk for the launcher and
 // for the workspace size, so the two cannot disagree.  Two items that write the same dw (one conv used twice in a backward:
 // overwrite, then accumulate) must neither share a launch -- the overwrite and the read-modify-write would race -- nor change
 // their order: whatever is pending goes first.
