@@ -1416,7 +1416,7 @@ static void launch_gather(GatherArgs& a, hipStream_t st) {
     else a.bnb_partial = nullptr;
   }
   constexpr bool EXTRAS = !HM_OUT && BM <= 128 && !CAT && KG == 1;     // the BatchNorm-backward epilogue exists for the regular tiles only
-  constexpr bool STATS = !HM_OUT && (BM <= 128 || (BM == 256 && BN == 128));   // statistics: also the 256x128 macro tile
+  constexpr bool STATS = !HM_OUT && (BM <= 128 || (BM == 256 && BN == 128) || (BM == 256 && BN == 256 && DMA));   // statistics: also the 256x128 macro tile and the 256x256 LDS-DMA build
   if (!EXTRAS && a.bnb_partial) a.bnb_partial = nullptr;
   static const bool stats256 = !(getenv("MI355_STATS_256") && atoi(getenv("MI355_STATS_256")) == 0);      // A/B switch
   if ((!STATS || (BM == 256 && !stats256)) && a.stat_partial) { a.stat_partial = nullptr; a.stat_slices = 0; }
@@ -1491,6 +1491,9 @@ static int dispatch_gather(GatherArgs& a, hipStream_t st) {
     const long t128 = cdiv(Mtot, 128L) * cdiv(a.Nout, 128);
     // 3x3 / unit stride / same-size maps of a power-of-two width <= 128: the A-tile-sharing variant (see KW3 above)
     static const int kw3_on = getenv("MI355_KW3") ? atoi(getenv("MI355_KW3")) : 1;
+    static const int t256d = getenv("MI355_T256D") ? atoi(getenv("MI355_T256D")) : 1;                      // A/B switch: 256 x 256 LDS-DMA tiles (30.41 / 30.42 -> 30.15 / 30.18 ms; with 128 .. 191 tiles too: slower)
+    static const long t256d_min = getenv("MI355_T256D_MIN") ? atol(getenv("MI355_T256D_MIN")) : 192;
+    static const long t256d_kmin = getenv("MI355_T256D_KMIN") ? atol(getenv("MI355_T256D_KMIN")) : 32;
     static const int splitk_on = getenv("MI355_SPLITK") ? atoi(getenv("MI355_SPLITK")) : 2;                 // A/B switch (1: 128 x 128 tiles only)
     const long t64 = cdiv(Mtot, 64L) * cdiv(a.Nout, 128);
     static const long splitk_min = getenv("MI355_SPLITK_MIN") ? atol(getenv("MI355_SPLITK_MIN")) : 128;
@@ -1513,6 +1516,12 @@ static int dispatch_gather(GatherArgs& a, hipStream_t st) {
       if (kw3 && (cdiv(Mtot, 128L) >= 2048 || kw3_on == 2)) { if constexpr (sizeof(T) == 2) launch_gather<T, 128, 64, false, 2, 2, false, false, true>(a, st); }
       else if (cdiv(Mtot, 128L) >= 512) launch_gather<T, 128, 64, false>(a, st); else launch_gather<T, 64, 64, false>(a, st);
     } else if (sizeof(T) == 2 && getenv("MI355_T256") && a.Nout % 256 == 0 && cdiv(Mtot, 256L) * (a.Nout / 256) >= 256) launch_gather<T, 256, 256, false, 2, 4>(a, st);
+    // one 256 x 256 tile per CU on the LDS-DMA ring (8 waves, 128 accumulators each): half the bytes through L1 per MFMA of the 128 x 128
+    // tiles, for launches that offer one round of such tiles
+    else if (t256d && sizeof(T) == 2 && a.nphase == 1 && a.Nout % 256 == 0 && dma_mode == 1 && !a.bnb_partial &&
+             cdiv(Mtot, 256L) * (a.Nout / 256) >= t256d_min && cdiv(Mtot, 256L) * (a.Nout / 256) <= 256 && kavg >= t256d_kmin) {
+      if constexpr (sizeof(T) == 2) launch_gather<T, 256, 256, false, 2, 4, false, true>(a, st);
+    }
     // LDS-DMA ring for K-heavy layers (>= 16 K-tiles): +9..12 % on the 3x3 / 4x4 convs, but -15 % on short-K 1x1 convs
     // (2 blocks/CU instead of 3), so those keep the register-staged form.  MI355_DMA=0 disables, =2 forces (tests).
     // (measured: 334 -> 310 us forward, 324 -> 312 us dgrad on 256->256 @64x64; at 1024 tiles the LDS-DMA ring still wins)

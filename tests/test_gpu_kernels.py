@@ -68,6 +68,8 @@ CONV_CASES = [
     (64, 512, 8, 8, 512, 3, 1, 1),    # 128 tiles of 128 x 128: 64-row tiles with two K groups per workgroup (3x3 512->512 @8x8, B=64)
     (64, 1024, 16, 16, 256, 1, 1, 0),  # 256 tiles, K = 1024 in one tap: two K groups on a 1x1 conv (1024->256 @16x16, B=64)
     (64, 64, 64, 64, 64, 3, 1, 1),     # 2048 tiles of 128 x 64: the shared-A-tile (KW3) kernel's build for 64 output channels (layer1's 3x3 convs, B=64)
+    (64, 256, 16, 16, 1024, 1, 1, 0),  # 256 tiles of 256 x 256 (forward; short K): the one-tile-per-CU LDS-DMA build where it is dispatched
+    (64, 256, 32, 32, 256, 3, 1, 1),   # 256 tiles of 256 x 256, K = 2304 (3x3 256->256 @32x32, B=64)
 ]
 
 
