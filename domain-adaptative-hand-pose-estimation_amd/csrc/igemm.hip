@@ -1430,6 +1430,16 @@ static void launch_gather(GatherArgs& a, hipStream_t st) {
   launch_gather_epi<T, BM, BN, SMALL_C, WGM, WGN, HM_OUT, DMA, 0, KW3, CAT, KG>(a, st);
 }
 
+// Do the 256 x 256 tiles of this launch fill whole rounds of 256 CUs (one 8-wave block per CU)?  mode 1: exactly one round of
+// >= tmin tiles; mode 2 (experiment): up to four rounds, the last one with >= tmin tiles, phases of a strided launch counted separately.
+static bool t256_fits(const GatherArgs& a, long Mtot, int mode, long tmin) {
+  (void)Mtot;
+  long t = 0;
+  for (int i = 0; i < a.nphase; ++i) t += cdiv(a.ph[i].M, 256L) * (a.Nout / 256);
+  if (mode < 2) return t >= tmin && t <= 256;
+  const long rem = t % 256;
+  return t >= tmin && t <= 1024 && (rem == 0 || rem >= tmin);
+}
 template <typename T>
 static int dispatch_gather(GatherArgs& a, hipStream_t st) {
   constexpr int CH = MmaTraits<T>::CH;
@@ -1467,7 +1477,12 @@ static int dispatch_gather(GatherArgs& a, hipStream_t st) {
     if (a.c2 < CH || a.c2 % CH || a.c2 > MmaTraits<T>::BK) MI_FAIL(MI355_EINVAL, "concat-K forward: c2=%d must be a multiple of %d and <= %d", a.c2, CH, MmaTraits<T>::BK);
     const long t128 = cdiv(Mtot, 128L) * cdiv(a.Nout, 128);
     static const int cat_tile = getenv("MI355_CAT_TILE") ? atoi(getenv("MI355_CAT_TILE")) : 0;     // experiment switch
-    if (cat_tile == 1 && a.Nout > 64) launch_gather<T, 128, 128, false, 2, 2, false, false, false, true>(a, st);
+    static const int t256d_cat = getenv("MI355_T256D") ? atoi(getenv("MI355_T256D")) : 2;
+    static const long t256d_cmin = getenv("MI355_T256D_MIN") ? atol(getenv("MI355_T256D_MIN")) : 192;
+    if (t256d_cat >= 2 && sizeof(T) == 2 && a.Nout % 256 == 0 && dma_mode == 1 && t256_fits(a, Mtot, t256d_cat, t256d_cmin)) {
+      if constexpr (sizeof(T) == 2) launch_gather<T, 256, 256, false, 2, 4, false, true, false, true>(a, st);
+    }
+    else if (cat_tile == 1 && a.Nout > 64) launch_gather<T, 128, 128, false, 2, 2, false, false, false, true>(a, st);
     else if (cat_tile == 2 && a.Nout > 64) launch_gather<T, 128, 128, false, 2, 2, false, true, false, true>(a, st);
     else if (cat_tile == 3 && a.Nout > 64) launch_gather<T, 64, 128, false, 2, 2, false, false, false, true>(a, st);
     else if (a.Nout <= 64) launch_gather<T, 64, 64, false, 2, 2, false, false, false, true>(a, st);
@@ -1491,7 +1506,9 @@ static int dispatch_gather(GatherArgs& a, hipStream_t st) {
     const long t128 = cdiv(Mtot, 128L) * cdiv(a.Nout, 128);
     // 3x3 / unit stride / same-size maps of a power-of-two width <= 128: the A-tile-sharing variant (see KW3 above)
     static const int kw3_on = getenv("MI355_KW3") ? atoi(getenv("MI355_KW3")) : 1;
-    static const int t256d = getenv("MI355_T256D") ? atoi(getenv("MI355_T256D")) : 1;                      // A/B switch: 256 x 256 LDS-DMA tiles (30.41 / 30.42 -> 30.15 / 30.18 ms; with 128 .. 191 tiles too: slower)
+    // A/B switch: 256 x 256 LDS-DMA tiles.  1: launches of ONE round of tiles (30.41 / 30.42 -> 30.15 / 30.18 ms; with 128 .. 191 tiles too:
+    // slower); 2 (default): also up to four full rounds, the phases of strided input gradients / transposed convs, the concat-K forward
+    static const int t256d = getenv("MI355_T256D") ? atoi(getenv("MI355_T256D")) : 2;
     static const long t256d_min = getenv("MI355_T256D_MIN") ? atol(getenv("MI355_T256D_MIN")) : 192;
     static const long t256d_kmin = getenv("MI355_T256D_KMIN") ? atol(getenv("MI355_T256D_KMIN")) : 32;
     static const int splitk_on = getenv("MI355_SPLITK") ? atoi(getenv("MI355_SPLITK")) : 2;                 // A/B switch (1: 128 x 128 tiles only)
@@ -1518,8 +1535,10 @@ static int dispatch_gather(GatherArgs& a, hipStream_t st) {
     } else if (sizeof(T) == 2 && getenv("MI355_T256") && a.Nout % 256 == 0 && cdiv(Mtot, 256L) * (a.Nout / 256) >= 256) launch_gather<T, 256, 256, false, 2, 4>(a, st);
     // one 256 x 256 tile per CU on the LDS-DMA ring (8 waves, 128 accumulators each): half the bytes through L1 per MFMA of the 128 x 128
     // tiles, for launches that offer one round of such tiles
-    else if (t256d && sizeof(T) == 2 && a.nphase == 1 && a.Nout % 256 == 0 && dma_mode == 1 && !a.bnb_partial &&
-             cdiv(Mtot, 256L) * (a.Nout / 256) >= t256d_min && cdiv(Mtot, 256L) * (a.Nout / 256) <= 256 && kavg >= t256d_kmin) {
+    // (not the accumulating epilogues: their read-modify-write of a 128-KB tile has no second block on the CU to hide behind --
+    //  1x1 1024 -> 256 @16x16 input gradient + masked accumulate 20.8 -> 25.2 us, 256 -> 256 @64x64 + accumulate 93 -> 112 us)
+    else if (t256d && sizeof(T) == 2 && (a.nphase == 1 || t256d >= 2) && a.Nout % 256 == 0 && dma_mode == 1 && !a.bnb_partial && !a.accumulate &&
+             t256_fits(a, Mtot, t256d, t256d_min) && kavg >= t256d_kmin) {
       if constexpr (sizeof(T) == 2) launch_gather<T, 256, 256, false, 2, 4, false, true>(a, st);
     }
     // LDS-DMA ring for K-heavy layers (>= 16 K-tiles): +9..12 % on the 3x3 / 4x4 convs, but -15 % on short-K 1x1 convs
