@@ -1538,7 +1538,7 @@ static int dispatch_gather(GatherArgs& a, hipStream_t st) {
     // (not the accumulating epilogues: their read-modify-write of a 128-KB tile has no second block on the CU to hide behind --
     //  1x1 1024 -> 256 @16x16 input gradient + masked accumulate 20.8 -> 25.2 us, 256 -> 256 @64x64 + accumulate 93 -> 112 us)
     else if (t256d && sizeof(T) == 2 && (a.nphase == 1 || t256d >= 2) && a.Nout % 256 == 0 && dma_mode == 1 && !a.bnb_partial && !a.accumulate &&
-             t256_fits(a, Mtot, t256d, t256d_min) && kavg >= t256d_kmin) {
+             t256_fits(a, Mtot, t256d, t256d_min) && kavg >= t256d_kmin && !(kw3 && t128 >= 2048)) {      // (the big 3x3 layers keep the shared-A-tile kernels: 309.7 vs 312.7 us)
       if constexpr (sizeof(T) == 2) launch_gather<T, 256, 256, false, 2, 4, false, true>(a, st);
     }
     // LDS-DMA ring for K-heavy layers (>= 16 K-tiles): +9..12 % on the 3x3 / 4x4 convs, but -15 % on short-K 1x1 convs
